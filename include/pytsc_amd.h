@@ -1,0 +1,281 @@
+/*
+ * pytsc_amd.h — C-ABI of the MI355X-native batched traffic-signal environment.
+ *
+ * This is the drop-in boundary for the hot path `TrafficSignalNetwork.step()`
+ * (reference: pytsc/__init__.py:178-182).  The reference has no FFI of its own:
+ * its boundary is a Python class registry (pytsc/__init__.py:11-14,
+ * pytsc/backends/cityflow/__init__.py:18-26) on top of the pybind module
+ * `cityflow.Engine`.  The entry points below are what a `pytsc.backends.<name>`
+ * backend binds (via ctypes) instead of `cityflow.Engine`:
+ *
+ *   tsc_create        <- cityflow.Engine(config_file, thread_num)
+ *                        (pytsc/backends/cityflow/simulator.py:64-78) for R replicas
+ *   tsc_reset         <- Engine.reset() + new Engine (simulator.py:91-95,
+ *                        pytsc/__init__.py:164-176)
+ *   tsc_step          <- action_space.apply + 5 x Engine.next_step +
+ *                        retrieve_step_measurements + update_stats + get_reward
+ *                        (pytsc/__init__.py:178-182; actions.py:99-108,144-158;
+ *                        simulator.py:80-89; retriever.py:54-112;
+ *                        backends/cityflow/traffic_signal.py:101-141)
+ *                        and the getters the callers pull right after:
+ *                        get_observations / get_state / get_rewards /
+ *                        get_action_mask (observations.py:140-160,183-205;
+ *                        reward.py:54-88; actions.py:119-131,169-188)
+ *   tsc_lane_detail   <- Engine.get_lane_vehicles / get_vehicle_info based
+ *                        per-lane position matrices (retriever.py:20-52) for the
+ *                        single-replica facade objects the rule-based
+ *                        controllers read (controllers/controllers.py:93-242)
+ *   tsc_snapshot      <- Engine.get_lane_vehicles/get_vehicle_speed/
+ *                        get_vehicle_info dumps (debug / parity)
+ *   tsc_destroy       <- Engine destructor
+ *
+ * Conventions: plain pointers and sizes only; `*_dev` pointers are caller-owned
+ * DEVICE buffers (e.g. torch tensors' data_ptr()); tables are HOST pointers
+ * copied at create time; `stream` is a hipStream_t passed as void* (NULL = the
+ * null stream); every call returns 0 on success or a negative TSC_E* code and
+ * never blocks the host except tsc_create/tsc_destroy/tsc_snapshot/tsc_errors.
+ * No internal host threads; one handle per GPU.
+ *
+ * The same table structs are consumed by the CPU oracle (oracle/tsc_oracle.h),
+ * which is test infrastructure only.
+ */
+#ifndef PYTSC_AMD_H
+#define PYTSC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSC_ABI_VERSION 1
+
+/* error codes */
+#define TSC_OK 0
+#define TSC_EINVAL (-1)   /* bad argument / inconsistent tables            */
+#define TSC_ENODEV (-2)   /* no usable GPU / HIP failure                   */
+#define TSC_ENOMEM (-3)
+#define TSC_EUNSUP (-4)   /* table uses a feature the HIP path rejects     */
+
+/* vehicle template: doubles per template (flow JSON "vehicle" object) */
+#define TSC_TMPL_STRIDE 12
+#define TSC_T_LEN 0
+#define TSC_T_WIDTH 1
+#define TSC_T_MAXPOSACC 2
+#define TSC_T_MAXNEGACC 3
+#define TSC_T_USUALPOSACC 4
+#define TSC_T_USUALNEGACC 5
+#define TSC_T_MINGAP 6
+#define TSC_T_MAXSPEED 7
+#define TSC_T_HEADWAY 8
+#define TSC_T_YIELDDIST 9
+#define TSC_T_TURNSPEED 10
+#define TSC_T_APPROACH 11 /* maxSpeed^2/(2 usualNegAcc) + 2 maxSpeed dt */
+
+/* road-link types, numeric order is the yielding priority */
+#define TSC_LINK_RIGHT 1
+#define TSC_LINK_LEFT 2
+#define TSC_LINK_STRAIGHT 3
+
+/* observation geometry (reference: common/observations.py:59-63,175-181,207-213) */
+#define TSC_MAX_CTRL_LANES 16
+#define TSC_MAX_PHASES 20
+#define TSC_LANE_STATIC 9
+#define TSC_MAX_AGENT_PHASES 32 /* PyTSC phase-list entries per agent (table limit) */
+
+/* action spaces (reference: common/actions.py:87,134) */
+#define TSC_ACT_PHASE_SELECTION 0
+#define TSC_ACT_PHASE_SWITCH 1
+
+/* stats columns of tsc_step's `stats` output (reference: backends/cityflow/metrics.py:221-260) */
+#define TSC_N_STATS 8
+#define TSC_S_TIME_STEP 0
+#define TSC_S_AVG_TRAVEL_TIME 1
+#define TSC_S_N_QUEUED 2
+#define TSC_S_MEAN_SPEED 3
+#define TSC_S_MEAN_DELAY 4
+#define TSC_S_DENSITY 5
+#define TSC_S_PRESSURE 6
+#define TSC_S_NETWORK_FLOW 7
+
+/* per-agent stats columns (reference: backends/cityflow/traffic_signal.py:101-141) */
+#define TSC_N_AGENT_STATS 8
+#define TSC_A_N_QUEUED 0
+#define TSC_A_OCCUPANCY 1
+#define TSC_A_MEAN_SPEED 2
+#define TSC_A_MEAN_DELAY 3
+#define TSC_A_OUT_OCCUPANCY 4
+#define TSC_A_PRESSURE 5
+#define TSC_A_NORM_TIME_ON_PHASE 6
+#define TSC_A_SIM_STEP_NORM 7
+
+/*
+ * Static network tables (shared by all replicas).  Drivable index space:
+ * lanes first, [0, n_lanes), in *sorted lane-id order* (the order of
+ * std::map keys that cityflow's getters return and PyTSC iterates,
+ * retriever.py:66, network_parser.py:104-118); lane-links follow,
+ * [n_lanes, n_lanes + n_links), in roadnet-file order (intersection, roadLink,
+ * laneLink).  Agents are in roadnet-file intersection order
+ * (network_parser.py:48-51).
+ */
+typedef struct tsc_net {
+  int32_t n_lanes;
+  int32_t n_links;
+  int32_t n_agents;
+  int32_t n_routes;
+  int32_t n_tmpl;
+  int32_t n_raw_phases_max;
+
+  /* drivables [n_lanes + n_links] */
+  const double *drv_length;     /* engine length: trimmed lane / polyline of link */
+  const double *drv_max_speed;  /* lane maxSpeed; 10000 for lane-links            */
+  const int32_t *drv_cap;       /* slot capacity                                  */
+
+  /* lanes [n_lanes] */
+  const int32_t *lane_out_ptr;  /* [n_lanes+1] CSR: lane-links leaving the lane   */
+  const int32_t *lane_out_links;/*   drivable indices, roadnet-file order         */
+  const int32_t *lane_in_ptr;   /* [n_lanes+1] CSR: lane-links ending in the lane */
+  const int32_t *lane_in_links;
+  const double *lane_len_pytsc; /* centre-to-centre length (network_parser.py:325-352) */
+  const int32_t *lane_bins;     /* int(len_pytsc / veh_size_min_gap)              */
+  const int32_t *lane_static;   /* [n_lanes*9] truncated static features (Q1)     */
+
+  /* lane-links [n_links] (index = drivable index - n_lanes) */
+  const int32_t *link_start_lane;
+  const int32_t *link_end_lane;
+  const int32_t *link_type;       /* TSC_LINK_*                                  */
+  const int32_t *link_agent;      /* owning agent index                          */
+  const uint32_t *link_avail_mask;/* bit p set: available in raw light-phase p   */
+  const int32_t *link_cross_ptr;  /* [n_links+1] CSR, sorted by cross_dist_self  */
+  const int32_t *cross_other;     /* other lane-link (drivable index)            */
+  const double *cross_dist_self;  /* distance of the cross on this link          */
+  const double *cross_dist_other; /* distance of the cross on the other link     */
+
+  /* agents [n_agents] */
+  const int32_t *agent_n_phases;  /* PyTSC phase-list length                      */
+  const int32_t *agent_phase_raw; /* [n_agents*TSC_MAX_AGENT_PHASES] raw phase id */
+  const int32_t *agent_phase_green;/* [..] 1 = green index, 0 = yellow            */
+  const int32_t *agent_phase_min; /* [..] min_time of that entry's raw phase      */
+  const int32_t *agent_phase_max; /* [..] max_time                                */
+  const int32_t *agent_inc_ptr;   /* [n_agents+1] CSR incoming lanes (sorted ids) */
+  const int32_t *agent_inc_lanes;
+  const int32_t *agent_out_ptr;   /* [n_agents+1] CSR outgoing lanes (sorted ids) */
+  const int32_t *agent_out_lanes;
+  const int32_t *agent_nbr_ptr;   /* [n_agents+1] CSR k-hop neighbours, k-major   */
+  const int32_t *agent_nbr;       /*   neighbour agent index                      */
+  const double *agent_nbr_w;      /*   gamma**k                                   */
+
+  /* routes */
+  const int32_t *route_ptr;       /* [n_routes+1] CSR */
+  const int32_t *route_drv;       /* lane, link, lane, ..., lane */
+
+  /* vehicle templates [n_tmpl*TSC_TMPL_STRIDE] */
+  const double *tmpl;
+} tsc_net_t;
+
+/*
+ * Flow sets: F alternative demand files; replica r uses set
+ * (set_offset + r) % n_sets after each (re)start, advancing per restart when
+ * `sequential` (reference: backends/cityflow/config.py:63-76).  A vehicle id
+ * ("vid") is the rank of the vehicle in creation order (creation step, flow
+ * index, count) inside its set.
+ */
+typedef struct tsc_flows {
+  int32_t n_sets;
+  int32_t sim_len;               /* engine steps covered by the prefix tables     */
+  const int32_t *set_veh_ptr;    /* [n_sets+1] offsets into veh_*                 */
+  const int32_t *veh_route;
+  const int32_t *veh_start;      /* creation step                                 */
+  const int32_t *veh_tmpl;
+  const int32_t *spawn_ptr;      /* [n_sets*n_lanes+1] CSR over (set, lane)       */
+  const int32_t *spawn_vid;      /*   vids waiting order (creation order)         */
+  const int32_t *created_cnt;    /* [n_sets*(sim_len+2)] vehicles created at steps < t */
+  const int64_t *created_tsum;   /* [n_sets*(sim_len+2)] sum of their creation times  */
+} tsc_flows_t;
+
+typedef struct tsc_config {
+  int32_t n_replicas;
+  int32_t delta_time;            /* engine sub-steps per env step (5)             */
+  int32_t yellow_time;           /* == delta_time (backends/cityflow/config.py:58-61) */
+  int32_t action_space;          /* TSC_ACT_*                                     */
+  int32_t round_robin;           /* TLSRoundRobinPhaseSelectLogic vs Free         */
+  int32_t visibility;            /* bins (10)                                     */
+  int32_t sim_length;            /* 3600                                          */
+  int32_t episode_limit;         /* 360                                           */
+  int32_t initial_wait_time;     /* 0                                             */
+  int32_t set_offset;            /* first flow set of replica 0                   */
+  int32_t sequential_sets;       /* advance set on every restart                  */
+  int32_t reward_kind;           /* 0 queue_length, 1 max_pressure                */
+  double interval;               /* engine dt (1.0)                               */
+  double veh_size_min_gap;       /* 7.5                                           */
+  double flickering_coef;        /* 0.01                                          */
+} tsc_config_t;
+
+/* Optional outputs of tsc_step; any pointer may be NULL (skipped). */
+typedef struct tsc_step_out {
+  float *obs_dev;            /* [R, A, 16*(9+vis)+20]  PositionMatrix obs          */
+  float *state_dev;          /* [R, A, 16*12+20]       lane-feature state          */
+  uint8_t *mask_dev;         /* [R, A, n_actions]      n_actions = 16|max n_phases or 2 */
+  float *local_reward_dev;   /* [R, A]                                            */
+  float *global_reward_dev;  /* [R]                                               */
+  uint8_t *done_dev;         /* [R]  episode_over                                 */
+  uint8_t *terminated_dev;   /* [R]  sim_step == sim_length                       */
+  double *stats_dev;         /* [R, TSC_N_STATS]                                  */
+  double *agent_stats_dev;   /* [R, A, TSC_N_AGENT_STATS]                         */
+  int32_t *phase_dev;        /* [R, A, 3] current index, time_on_phase, phase_changed */
+  double *local_reward64_dev;/* [R, A]  f64 copies for parity checks              */
+  double *global_reward64_dev;/* [R] */
+} tsc_step_out_t;
+
+typedef struct tsc_env *tsc_handle_t;
+
+int tsc_abi_version(void);
+
+int tsc_create(const tsc_net_t *net, const tsc_flows_t *flows,
+               const tsc_config_t *cfg, int device, tsc_handle_t *out);
+int tsc_destroy(tsc_handle_t h);
+
+/* Restart replicas with reset_mask_dev[r] != 0 (NULL = all): empties the
+ * network, rewinds time, re-applies the start phase and runs
+ * initial_wait_time warm-up sub-steps. */
+int tsc_reset(tsc_handle_t h, const uint8_t *reset_mask_dev, void *stream);
+
+/* One env step for all replicas: apply actions_dev[R, A], advance delta_time
+ * engine sub-steps, measure, and fill the requested outputs. */
+int tsc_step(tsc_handle_t h, const int32_t *actions_dev,
+             const tsc_step_out_t *out, void *stream);
+
+/* Measure + fill outputs without stepping (state right after create/reset). */
+int tsc_observe(tsc_handle_t h, const tsc_step_out_t *out, void *stream);
+
+/* Per-lane measurements of the last measure pass:
+ *  lane_counts_dev [R, n_lanes, 2] (n_vehicles, n_queued) int32
+ *  lane_speed_dev  [R, n_lanes]    sum of speeds (mean_speed = sum / n) double
+ *  posmat_dev      [R, n_lanes, max_bins] full position matrices (double),
+ *                  max_bins = max(max lane_bins, visibility); may be NULL. */
+int tsc_lane_detail(tsc_handle_t h, int32_t *lane_counts_dev,
+                    double *lane_speed_dev, double *posmat_dev,
+                    int32_t max_bins, void *stream);
+
+/* Synchronous dump of one replica's vehicles to HOST arrays (capacity `cap`):
+ * drivable index, distance, speed, vid.  Returns the vehicle count (>= 0) or a
+ * negative error.  Vehicles inserted for the *next* sub-step are excluded. */
+int tsc_snapshot(tsc_handle_t h, int32_t replica, int32_t cap, int32_t *drv,
+                 double *dist, double *speed, int32_t *vid);
+
+/* Synchronous: device-side error counters (slot overflow etc.), 0 = clean. */
+int tsc_errors(tsc_handle_t h, int32_t *n_errors);
+
+/* Mean number of running vehicles per replica at the last measure pass
+ * (synchronous; used for reporting V_a). */
+int tsc_mean_vehicles(tsc_handle_t h, double *mean);
+
+/* Sizes derived from the tables. */
+int tsc_obs_size(tsc_handle_t h);
+int tsc_state_size(tsc_handle_t h);
+int tsc_n_actions(tsc_handle_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYTSC_AMD_H */

@@ -1,0 +1,98 @@
+"""Configuration: default YAML <- scenario YAML <- kwargs, three-level dict merge.
+
+Same behaviour as the reference (pytsc/common/config.py:37-70,
+pytsc/backends/cityflow/config.py:20-76): sections ``network``, ``signal``,
+``misc`` and the backend section, exposed as ``.network/.signal/.misc/.simulator``.
+Scenario directories in the reference's layout (``config.yaml`` + roadnet +
+flow JSONs) are accepted as-is: a ``cityflow:`` section is read as the backend
+section, so a PyTSC user can point ``scenario_dir`` at their existing scenarios.
+Synthetic scenarios named ``syn_<rows>x<cols>`` that have no directory are
+generated on the fly (pytsc_amd/grid.py, pytsc_amd/flows.py).
+"""
+import copy
+import os
+import random
+import re
+from itertools import cycle
+
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENARIO_ROOT = os.path.join(HERE, "scenarios")
+BACKEND = "hip"
+
+
+def recursively_update_dict(d, u):
+    for k, v in u.items():
+        if isinstance(v, dict):
+            d[k] = recursively_update_dict(d.get(k, {}), v)
+        else:
+            d[k] = v
+    return d
+
+
+class Config:
+    def __init__(self, scenario, scenario_dir=None, debug=True, **kwargs):
+        self.scenario = scenario
+        self.debug = debug
+        self._additional_config = kwargs
+        with open(os.path.join(SCENARIO_ROOT, "default", "config.yaml"), "r") as f:
+            cfg = yaml.safe_load(f)
+        if scenario_dir is None:
+            scenario_dir = os.path.join(SCENARIO_ROOT, BACKEND, scenario)
+        self.dir = os.path.join(os.path.abspath(scenario_dir), "")
+        scen_yaml = os.path.join(self.dir, "config.yaml")
+        if os.path.exists(scen_yaml):
+            with open(scen_yaml, "r") as f:
+                scen = yaml.safe_load(f) or {}
+            scen = copy.deepcopy(scen)
+            if "cityflow" in scen:  # reference-layout scenario
+                recursively_update_dict(cfg[BACKEND], scen.pop("cityflow"))
+            recursively_update_dict(cfg, scen)
+        extra = copy.deepcopy(kwargs)
+        if "cityflow" in extra:
+            recursively_update_dict(cfg[BACKEND], extra.pop("cityflow"))
+        for k in list(extra.keys()):
+            if k not in ("network", "signal", "misc", BACKEND):
+                extra.pop(k)
+        recursively_update_dict(cfg, extra)
+        self.network = cfg["network"]
+        self.signal = cfg["signal"]
+        self.misc = cfg["misc"]
+        self.simulator = cfg[BACKEND]
+        self.synthetic_grid = None
+        m = re.fullmatch(r"syn_(\d+)x(\d+)", scenario)
+        if "roadnet_json" in self.simulator:  # in-memory roadnet dict (tests, fixtures)
+            self.roadnet_file = None
+        elif "roadnet_file" in self.simulator:
+            self.roadnet_file = os.path.join(self.dir, self.simulator["roadnet_file"])
+        elif m:
+            self.synthetic_grid = (int(m.group(1)), int(m.group(2)))
+            self.roadnet_file = None
+        else:
+            raise FileNotFoundError(
+                f"scenario {scenario!r}: no roadnet_file in {scen_yaml} and not a syn_RxC name"
+            )
+        self.flow_files_cycle = cycle(self.simulator.get("flow_files", []))
+        self.flow_file = None
+        # backends/cityflow/config.py:58-61
+        assert (
+            self.signal["yellow_time"] == self.simulator["delta_time"]
+        ), "Delta time and yellow times must be fixed to 5 seconds."
+        random.seed(self.simulator["seed"])
+
+    def _set_flow_file(self):
+        """Flow-file selection per (re)start (backends/cityflow/config.py:63-76)."""
+        kind = self.simulator.get("flow_rate_type", "constant")
+        if kind == "constant":
+            self.flow_file = self.simulator.get("flow_file")
+        elif kind == "random":
+            self.flow_file = random.choice(self.simulator["flow_files"])
+        elif kind == "sequential":
+            self.flow_file = next(self.flow_files_cycle)
+        else:
+            raise ValueError(
+                "Flow files order is not supported. "
+                + "Flow files order must be `random` or `constant`"
+            )
+        return self.flow_file

@@ -1,0 +1,78 @@
+// Device-side views of the static tables and the dynamic state (gfx950 only).
+//
+// HBM layout: structure-of-arrays with the REPLICA index
+// fastest.  A wavefront is 64 consecutive replicas of ONE drivable (or one
+// agent), so every state access `arr[row * RS + r]` is a 256/512-byte coalesced
+// segment and every static-table access is wave-uniform (scalar loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pytsc_amd.h"
+
+#define TSC_CNT_MASK 0x3fffffff
+#define TSC_NEW_BIT 0x40000000
+#define TSC_TAG_VID(tag) ((tag) & 0xffffff)
+#define TSC_TAG_SEQ(tag) (((uint32_t)(tag)) >> 24)
+#define TSC_MAKE_TAG(vid, seq) ((int32_t)(((uint32_t)(vid)) | (((uint32_t)(seq)) << 24)))
+#define TSC_F_MOVED 1
+#define TSC_F_ENDED 2
+#define TSC_OB_MAX 3
+
+struct DevNet {
+  int n_lanes, n_links, n_drv, n_agents, n_routes, n_tmpl, single_tmpl;
+  int max_links_per_agent;
+  const double *drv_length, *drv_max_speed;
+  const int *drv_cap, *drv_slot_base;
+  const int *lane_out_ptr, *lane_out_links, *lane_in_ptr, *lane_in_links;
+  const double *lane_len_pytsc;
+  const int *lane_bins, *lane_static;
+  const int *link_start_lane, *link_end_lane, *link_type, *link_agent, *link_local;
+  const uint32_t *link_avail_mask;
+  const unsigned long long *link_conflict; // local-index mask of links crossing this link
+  const int *link_cross_ptr, *cross_other;
+  const double *cross_dist_self, *cross_dist_other;
+  const int *agent_link_ptr, *agent_links; // CSR: links of an agent in local order
+  const int *agent_n_phases, *agent_phase_raw, *agent_phase_green, *agent_phase_min, *agent_phase_max;
+  const int *agent_inc_ptr, *agent_inc_lanes, *agent_out_ptr, *agent_out_lanes;
+  const int *agent_nbr_ptr, *agent_nbr;
+  const double *agent_nbr_w;
+  const int *route_ptr, *route_drv;
+  const double *tmpl;
+  // flows
+  int n_sets, sim_len;
+  const int *set_veh_ptr, *veh_route, *veh_start, *veh_tmpl, *spawn_ptr, *spawn_vid, *created_cnt;
+  const long long *created_tsum;
+};
+
+struct DevState {
+  int R, RS; // replicas, row stride (R rounded up to 64)
+  // per slot [S_total * RS]
+  double *dist, *speed, *ndist, *nspeed;
+  int *tag, *aux, *blk, *nblk;
+  unsigned char *nflag;
+  // per drivable [n_drv * RS]
+  int *cnt, *ob, *tail_tag, *tail_prev;
+  int *obx_tag, *obx_aux, *obx_blk; // [n_drv * TSC_OB_MAX * RS] records of this sub-step's leavers
+  double *tail_dist, *tail_speed;
+  // per lane [n_lanes * RS]
+  int *spawn_cur, *lane_n, *lane_q;
+  double *lane_sum;
+  unsigned int *lane_in_bits, *lane_out_bits;
+  // per agent [n_agents * RS]
+  int *cur_idx, *top, *changed, *raw_phase;
+  unsigned long long *occ_e, *occ_v, *occ_s;
+  double *agent_local, *agent_pressure;
+  // per replica [RS]
+  int *t, *set, *restarts, *fin_cnt;
+  unsigned long long *fin_dsum, *fin_ssum; // sums over finished vehicles: duration, creation step
+  // per vid [max_veh * RS]
+  int *blocker_by_vid;
+  int *errors; // [4]: slot overflow, outbox overflow, bad action, other
+};
+
+struct DevCfg {
+  int delta_time, yellow_time, action_space, round_robin, visibility, sim_length, episode_limit;
+  int initial_wait_time, set_offset, sequential_sets, reward_kind, n_actions, obs_size, state_size;
+  double interval, veh_size_min_gap, flickering_coef;
+};

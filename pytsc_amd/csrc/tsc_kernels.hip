@@ -1,0 +1,1167 @@
+// Hand-written HIP kernels (gfx950 / CDNA4) of the batched traffic microsimulator:
+// the hot path TrafficSignalNetwork.step() (reference pytsc/__init__.py:178-182).
+//
+// Decomposition: lane-of-wave <-> env replica; a wavefront is 64
+// consecutive replicas of ONE drivable (lane or lane-link) or ONE agent, so HBM
+// accesses coalesce along the replica axis and topology is wave-uniform
+// (scalar loads, no divergence on the network structure).  One engine sub-step
+// is three launches (Jacobi update: decisions read the committed state):
+//   k_notify  (agent   x replica)  cross occupancy masks per intersection
+//   k_action  (drivable x replica) leader/gap, car-following, signal gating,
+//                                  cross yielding -> buffered speed/position
+//   k_commit  (drivable x replica) compaction, hand-off pull from feeder
+//                                  drivables, retire, spawn for the next step
+// and one env step ends with k_measure (lane x replica), k_agent (agent x
+// replica, observations staged through LDS for coalesced [R, A, obs] stores)
+// and k_stats (replica).  No MFMA: this is integer / f64 scalar work.
+//
+// f64 arithmetic follows the same operation order as the CPU oracle
+// (compiled with -ffp-contract=off on both sides) so results are bit-identical.
+#include "tsc_device.h"
+
+#define IDX(row) ((size_t)(row) * (size_t)S.RS + (size_t)r)
+
+struct Tm {
+  double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
+};
+
+__device__ __forceinline__ Tm load_tm(const DevNet &N, int id) {
+  const double *p = N.tmpl + (size_t)id * TSC_TMPL_STRIDE;
+  Tm t;
+  t.len = p[TSC_T_LEN];
+  t.maxPosAcc = p[TSC_T_MAXPOSACC];
+  t.maxNegAcc = p[TSC_T_MAXNEGACC];
+  t.usualNegAcc = p[TSC_T_USUALNEGACC];
+  t.minGap = p[TSC_T_MINGAP];
+  t.maxSpeed = p[TSC_T_MAXSPEED];
+  t.headway = p[TSC_T_HEADWAY];
+  t.yieldDist = p[TSC_T_YIELDDIST];
+  t.turnSpeed = p[TSC_T_TURNSPEED];
+  t.approach = p[TSC_T_APPROACH];
+  return t;
+}
+
+template <bool SINGLE>
+__device__ __forceinline__ int tmpl_of(const DevNet &N, int vbase, int vid) {
+  return SINGLE ? 0 : N.veh_tmpl[vbase + vid];
+}
+
+__device__ __forceinline__ double min2(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double max2(double a, double b) { return a > b ? a : b; }
+
+// C++ (int)x as x86-64 does it: out of range -> INT_MIN
+__device__ __forceinline__ int cvt_int(double x) {
+  if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
+  return (int)x;
+}
+
+// ---------------------------------------------------------------- kinematics
+__device__ __forceinline__ double min_brake_distance(double speed, const Tm &t) {
+  return 0.5 * speed * speed / t.maxNegAcc;
+}
+__device__ __forceinline__ bool can_yield(double speed, const Tm &t, double dist) {
+  return (dist > 0 && min_brake_distance(speed, t) < dist - t.yieldDist) || (dist < 0 && dist + t.len < 0);
+}
+__device__ __forceinline__ double distance_until_speed(double cur, double speed, double acc, double interval) {
+  if (speed <= cur) return 0;
+  int stage1steps = (int)floor((speed - cur) / acc / interval);
+  double stage1speed = cur + stage1steps * acc / interval;
+  double stage1dis = (cur + stage1speed) * (stage1steps * interval) / 2;
+  return stage1dis + (stage1speed < speed ? ((stage1speed + speed) * interval / 2) : 0);
+}
+__device__ __forceinline__ int reach_steps(double cur, double distance, double target, double acc, double interval) {
+  if (distance <= 0) return 0;
+  if (cur > target) return (int)ceil(distance / cur);
+  double dut = distance_until_speed(cur, target, acc, interval);
+  if (dut > distance) {
+    return (int)ceil((sqrt(cur * cur + 2 * acc * distance) - cur) / acc / interval);
+  } else {
+    return (int)ceil((target - cur) / acc / interval) + (int)ceil((distance - dut) / target / interval);
+  }
+}
+__device__ __forceinline__ double no_collision_speed(double vL, double dL, double vF, double dF, double gap,
+                                                     double interval, double targetGap) {
+  double c = vF * interval / 2 + targetGap - 0.5 * vL * vL / dL - gap;
+  double a = 0.5 / dF;
+  double b = 0.5 * interval;
+  if (b * b < 4 * a * c) return -100;
+  double v1 = 0.5 / a * (sqrt(b * b - 4 * a * c) - b);
+  double v2 = 2 * vL - dL * interval + 2 * (gap - targetGap) / interval;
+  return min2(v1, v2);
+}
+__device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, double vL, const Tm &tl, double gap,
+                                                   double interval) {
+  double s = no_collision_speed(vL, tl.maxNegAcc, speed, t.maxNegAcc, gap, interval, 0);
+  double assumeDecel = 0, leaderSpeed = vL;
+  if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
+  s = min2(s, no_collision_speed(vL, tl.usualNegAcc, speed, t.usualNegAcc, gap, interval, t.minGap));
+  s = min2(s, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) / (t.headway + interval / 2));
+  return s;
+}
+__device__ __forceinline__ double stop_before_speed(double speed, const Tm &t, double distance, double interval) {
+  double nextSpeed = speed + t.maxPosAcc * interval;
+  double bd = (speed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / t.usualNegAcc / 2);
+  if (bd < distance) return speed + t.maxPosAcc * interval;
+  double takeInterval = 2 * distance / (speed + 1e-9) / interval;
+  if (takeInterval >= 1) {
+    return speed - speed / cvt_int(takeInterval);
+  } else {
+    return speed - speed / takeInterval;
+  }
+}
+
+// XCD-aware block -> (replica block, row block) map: blocks b and b+8 share an
+// XCD (MI355X_MICROARCH.md, Workgroup dispatch), so all row-blocks of one
+// 64-replica block go to the same XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ bool map_block(int n_rb, int n_rowblk, int &rb, int &rowblk) {
+  int bid = blockIdx.x;
+  int xcd = bid & 7;
+  int j = bid >> 3;
+  rb = (j / n_rowblk) * 8 + xcd;
+  rowblk = j % n_rowblk;
+  return rb < n_rb;
+}
+static inline int grid_for(int n_rb, int n_rowblk) { return ((n_rb + 7) / 8) * 8 * n_rowblk; }
+
+// ------------------------------------------------------------------ k_notify
+// Per intersection: which lane-links currently have (E) a vehicle that just
+// left them as the tail of their end lane, (V) vehicles on them, (S) the head of
+// their start lane heading for them.  Restates the candidate set of the engine's
+// notifyCross as three 64-bit masks; the exact
+// per-cross foe is resolved lazily by find_foe() only for occupied links.
+__global__ __launch_bounds__(256) void k_notify(DevNet N, DevState S, int n_rb, int n_ablk) {
+  int rb, ablk;
+  if (!map_block(n_rb, n_ablk, rb, ablk)) return;
+  int a = __builtin_amdgcn_readfirstlane(ablk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (a >= N.n_agents || r >= S.R) return;
+  if (a == 0) S.t[r] += 1; // the step index being executed from here on
+  unsigned long long oe = 0, ov = 0, os = 0;
+  int lb = N.agent_link_ptr[a], le = N.agent_link_ptr[a + 1];
+  for (int li = lb; li < le; li++) {
+    int link = N.agent_links[li];
+    int k = link - N.n_lanes;
+    unsigned long long bit = 1ull << (li - lb);
+    if ((S.cnt[IDX(link)] & TSC_CNT_MASK) > 0) ov |= bit;
+    int e = N.link_end_lane[k];
+    int he = S.cnt[IDX(e)];
+    if ((he & TSC_CNT_MASK) > 0 && !(he & TSC_NEW_BIT) && S.tail_prev[IDX(e)] == link) oe |= bit;
+    int sl = N.link_start_lane[k];
+    int hs = S.cnt[IDX(sl)];
+    if ((hs & TSC_CNT_MASK) > 0 && S.aux[IDX(N.drv_slot_base[sl])] == link) os |= bit;
+  }
+  S.occ_e[IDX(a)] = oe;
+  S.occ_v[IDX(a)] = ov;
+  S.occ_s[IDX(a)] = os;
+}
+
+// ---------------------------------------------------------------- k_action
+struct Foe {
+  bool found;
+  double d2, speed;
+  int vid, ell, tmpl;
+};
+
+// The vehicle that the engine's notifyCross would have registered for the cross
+// at distance `xo` on lane-link `other`: first of (E, link vehicles front to
+// back, S) whose rear has not yet cleared the cross.
+template <bool SINGLE>
+__device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int r, int vbase, int other, double xo,
+                                        unsigned long long oe, unsigned long long ov, unsigned long long os,
+                                        int raw_phase) {
+  Foe f;
+  f.found = false;
+  f.d2 = 0;
+  f.speed = 0;
+  f.vid = -1;
+  f.ell = 0x7fffffff;
+  f.tmpl = 0;
+  int k = other - N.n_lanes;
+  unsigned long long bit = 1ull << N.link_local[k];
+  double Lo = N.drv_length[other];
+  if (oe & bit) {
+    int e = N.link_end_lane[k];
+    double td = S.tail_dist[IDX(e)];
+    int ttag = S.tail_tag[IDX(e)];
+    int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+    double tlen = N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+    double crossDistance = Lo - xo;
+    double vehDistance = td - tlen;
+    if (crossDistance + vehDistance < 0) {
+      f.found = true;
+      f.d2 = -(td + crossDistance);
+      f.speed = S.tail_speed[IDX(e)];
+      f.vid = TSC_TAG_VID(ttag);
+      f.tmpl = tt;
+      return f;
+    }
+  }
+  if (ov & bit) {
+    int n = S.cnt[IDX(other)] & TSC_CNT_MASK;
+    int sb = N.drv_slot_base[other];
+    for (int j = 0; j < n; j++) {
+      double dj = S.dist[IDX(sb + j)];
+      int tg = S.tag[IDX(sb + j)];
+      int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tg));
+      double tlen = N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+      bool claim;
+      if (dj > xo) claim = (dj - xo - tlen <= 0);
+      else claim = true;
+      if (claim) {
+        f.found = true;
+        f.d2 = xo - dj;
+        f.speed = S.speed[IDX(sb + j)];
+        f.vid = TSC_TAG_VID(tg);
+        f.ell = S.aux[IDX(sb + j)];
+        f.tmpl = tt;
+        return f;
+      }
+    }
+  }
+  if ((os & bit) && ((N.link_avail_mask[k] >> raw_phase) & 1u)) {
+    int sl = N.link_start_lane[k];
+    int s0 = N.drv_slot_base[sl];
+    double ds = S.dist[IDX(s0)];
+    int tg = S.tag[IDX(s0)];
+    f.found = true;
+    f.d2 = (N.drv_length[sl] - ds) + xo;
+    f.speed = S.speed[IDX(s0)];
+    f.vid = TSC_TAG_VID(tg);
+    f.tmpl = tmpl_of<SINGLE>(N, vbase, f.vid);
+  }
+  return f;
+}
+
+// Cross::canPass
+__device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &S, int r, double speed, const Tm &t,
+                                               int vid, int ell, int link, int other, double d1, const Foe &f,
+                                               double interval) {
+  Tm tf = load_tm(N, f.tmpl);
+  int t1 = N.link_type[link - N.n_lanes];
+  int t2 = N.link_type[other - N.n_lanes];
+  double d2 = f.d2;
+  if (!can_yield(speed, t, d1)) return true;
+  int yield = 0;
+  if (!can_yield(f.speed, tf, d2)) yield = 1;
+  if (yield == 0) {
+    double tgt1 = (t1 != TSC_LINK_STRAIGHT) ? t.turnSpeed : t.maxSpeed;
+    double tgt2 = (t2 != TSC_LINK_STRAIGHT) ? tf.turnSpeed : tf.maxSpeed;
+    if (t1 > t2) {
+      yield = -1;
+    } else if (t1 < t2) {
+      if (d2 > 0) {
+        int foeSteps = reach_steps(f.speed, d2, tgt2, tf.maxPosAcc, interval);
+        int mySteps = reach_steps(speed, d1, tgt1, t.maxPosAcc, interval);
+        if (foeSteps > mySteps) yield = -1;
+      } else {
+        if (d2 + tf.len < 0) yield = -1;
+      }
+      if (yield == 0) yield = 1;
+    } else {
+      if (d2 > 0) {
+        int foeSteps = reach_steps(f.speed, d2, tgt2, tf.maxPosAcc, interval);
+        int mySteps = reach_steps(speed, d1, tgt1, t.maxPosAcc, interval);
+        if (foeSteps > mySteps) {
+          yield = -1;
+        } else if (foeSteps < mySteps) {
+          yield = 1;
+        } else {
+          if (ell == f.ell) {
+            if (d1 == d2) yield = vid < f.vid ? -1 : 1;
+            else yield = d1 < d2 ? -1 : 1;
+          } else {
+            yield = ell < f.ell ? -1 : 1;
+          }
+        }
+      } else {
+        yield = d2 + tf.len < 0 ? -1 : 1;
+      }
+    }
+  }
+  if (yield == 1) {
+    // blocker-chain cycle check (Floyd) over the committed blockers
+    int fast = f.vid, slow = f.vid;
+    for (int guard = 0; guard < 4096; guard++) {
+      if (fast < 0) break;
+      int bf = S.blocker_by_vid[IDX(fast)];
+      if (bf < 0) break;
+      slow = S.blocker_by_vid[IDX(slow)];
+      fast = S.blocker_by_vid[IDX(bf)];
+      if (slow == fast) {
+        yield = -1;
+        break;
+      }
+    }
+  }
+  return yield == -1;
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, int n_rb, int n_dblk) {
+  int rb, dblk;
+  if (!map_block(n_rb, n_dblk, rb, dblk)) return;
+  int d = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (d >= N.n_drv || r >= S.R) return;
+  int hdr = S.cnt[IDX(d)];
+  int n = hdr & TSC_CNT_MASK;
+  if (n == 0) {
+    S.ob[IDX(d)] = 0;
+    return;
+  }
+  const double interval = C.interval;
+  const bool is_link = d >= N.n_lanes;
+  const double L = N.drv_length[d];
+  const double drvMax = N.drv_max_speed[d];
+  const int sb = N.drv_slot_base[d];
+  const int vbase = SINGLE ? 0 : N.set_veh_ptr[S.set[r]];
+  const int kd = is_link ? d - N.n_lanes : 0;
+  const int my_agent = is_link ? N.link_agent[kd] : -1;
+  const int end_lane = is_link ? N.link_end_lane[kd] : -1;
+
+  double p_dist = 0, p_speed = 0;
+  int p_tmpl = 0;
+  int ob = 0, n_out = 0;
+  for (int i = 0; i < n; i++) {
+    double dist = S.dist[IDX(sb + i)];
+    double speed = S.speed[IDX(sb + i)];
+    int tag = S.tag[IDX(sb + i)];
+    int aux = S.aux[IDX(sb + i)];
+    int vid = TSC_TAG_VID(tag);
+    int tid = tmpl_of<SINGLE>(N, vbase, vid);
+    Tm t = load_tm(N, tid);
+
+    // ---- leader and gap (engine: updateLeaderAndGap)
+    bool has_leader = false;
+    double gap = 0, vL = 0;
+    int l_tmpl = 0;
+    if (i > 0) {
+      has_leader = true;
+      double plen = N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+      gap = p_dist - plen - dist;
+      vL = p_speed;
+      l_tmpl = p_tmpl;
+    } else {
+      double dis = L - dist;
+      double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * interval * 2;
+      int lane_to_check = -1;
+      if (is_link) {
+        lane_to_check = end_lane;
+      } else if (aux >= 0) {
+        // all lane-links leaving this lane may overlap: nearest tail wins
+        for (int q = N.lane_out_ptr[d]; q < N.lane_out_ptr[d + 1]; q++) {
+          int ll = N.lane_out_links[q];
+          int nl = S.cnt[IDX(ll)] & TSC_CNT_MASK;
+          if (nl > 0) {
+            int ttag = S.tail_tag[IDX(ll)];
+            int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+            double cg = dis + S.tail_dist[IDX(ll)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+            if (!has_leader || cg < gap) {
+              has_leader = true;
+              gap = cg;
+              vL = S.tail_speed[IDX(ll)];
+              l_tmpl = tt;
+            }
+          }
+        }
+        if (!has_leader) {
+          dis += N.drv_length[aux];
+          if (!(dis > limit)) lane_to_check = N.link_end_lane[aux - N.n_lanes];
+        }
+      }
+      if (lane_to_check >= 0) {
+        int he = S.cnt[IDX(lane_to_check)];
+        int ne = (he & TSC_CNT_MASK) - ((he & TSC_NEW_BIT) ? 1 : 0); // tail before this step's insertion
+        if (ne > 0) {
+          int ttag = S.tail_tag[IDX(lane_to_check)];
+          int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+          has_leader = true;
+          gap = dis + S.tail_dist[IDX(lane_to_check)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+          vL = S.tail_speed[IDX(lane_to_check)];
+          l_tmpl = tt;
+        }
+        // beyond: a whole lane further is past the look-ahead limit (checked at create)
+      }
+    }
+
+    // ---- speed choice (engine: getNextSpeed)
+    double v = t.maxSpeed;
+    v = min2(v, speed + t.maxPosAcc * interval);
+    v = min2(v, drvMax);
+    if (has_leader) {
+      Tm tl = load_tm(N, l_tmpl);
+      v = min2(v, car_follow_speed(speed, t, vL, tl, gap, interval));
+    } else {
+      v = min2(v, t.maxSpeed);
+    }
+    int nblk = -1;
+    bool related = is_link || (aux >= 0 && (L - dist) <= t.approach);
+    if (related) {
+      double s = t.maxSpeed;
+      int link = is_link ? d : aux;
+      int k = link - N.n_lanes;
+      int ag = is_link ? my_agent : N.link_agent[k];
+      int raw = S.raw_phase[IDX(ag)];
+      bool done = false;
+      if (!is_link) {
+        bool avail = (N.link_avail_mask[k] >> raw) & 1u;
+        int e = N.link_end_lane[k];
+        int he = S.cnt[IDX(e)];
+        bool can_enter;
+        if ((he & TSC_CNT_MASK) == 0) can_enter = true;
+        else if (he & TSC_NEW_BIT) can_enter = false; // tail is a vehicle inserted this step: dist 0, speed 0
+        else {
+          int ttag = S.tail_tag[IDX(e)];
+          int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+          can_enter = S.tail_dist[IDX(e)] > N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN] + t.len ||
+                      S.tail_speed[IDX(e)] >= 2;
+        }
+        if (!avail || !can_enter) {
+          if (min_brake_distance(speed, t) > L - dist) {
+            // cannot brake before the stop line
+          } else {
+            s = min2(s, stop_before_speed(speed, t, L - dist, interval));
+            done = true;
+          }
+        }
+        if (!done && N.link_type[k] != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
+      }
+      if (!done) {
+        unsigned long long oe = S.occ_e[IDX(ag)], ov = S.occ_v[IDX(ag)], os = S.occ_s[IDX(ag)];
+        unsigned long long active = N.link_conflict[k] & (oe | ov | os);
+        if (active) {
+          double distanceToLaneLinkStart = is_link ? dist : -(L - dist);
+          int ell = is_link ? aux : 0x7fffffff;
+          for (int e = N.link_cross_ptr[k]; e < N.link_cross_ptr[k + 1]; e++) {
+            double x = N.cross_dist_self[e];
+            if (x < distanceToLaneLinkStart) continue;
+            int other = N.cross_other[e];
+            if (!((active >> N.link_local[other - N.n_lanes]) & 1ull)) continue;
+            Foe f = find_foe<SINGLE>(N, S, r, vbase, other, N.cross_dist_other[e], oe, ov, os, raw);
+            if (!f.found) continue;
+            double d1 = x - distanceToLaneLinkStart;
+            if (!cross_can_pass(N, S, r, speed, t, vid, ell, link, other, d1, f, interval)) {
+              s = min2(s, stop_before_speed(speed, t, x - distanceToLaneLinkStart - t.yieldDist, interval));
+              nblk = f.vid;
+              break;
+            }
+          }
+        }
+      }
+      v = min2(v, s);
+    }
+    v = max2(v, speed - t.maxNegAcc * interval);
+    double deltaDis;
+    if (v < 0) {
+      deltaDis = 0.5 * speed * speed / t.maxNegAcc;
+      v = 0;
+    } else {
+      deltaDis = (speed + v) * interval / 2;
+    }
+    // ---- move (engine: setDeltaDistance)
+    double nd = deltaDis + dist;
+    int fl = 0;
+    if (nd > L) {
+      nd -= L;
+      fl = TSC_F_MOVED;
+      if (!is_link && aux < 0) fl = TSC_F_MOVED | TSC_F_ENDED;
+      if (n_out < TSC_OB_MAX) {
+        ob |= (i & 1023) << (2 + 10 * n_out);
+        size_t ox = ((size_t)d * TSC_OB_MAX + n_out) * (size_t)S.RS + (size_t)r;
+        S.obx_tag[ox] = tag;
+        S.obx_aux[ox] = aux;
+        S.obx_blk[ox] = S.blk[IDX(sb + i)];
+      } else atomicAdd(&S.errors[1], 1);
+      n_out++;
+    }
+    S.ndist[IDX(sb + i)] = nd;
+    S.nspeed[IDX(sb + i)] = v;
+    S.nblk[IDX(sb + i)] = nblk;
+    S.nflag[IDX(sb + i)] = (unsigned char)fl;
+    p_dist = dist;
+    p_speed = speed;
+    p_tmpl = tid;
+  }
+  S.ob[IDX(d)] = ob | (n_out < TSC_OB_MAX ? n_out : TSC_OB_MAX);
+}
+
+// ---------------------------------------------------------------- k_commit
+template <bool SINGLE>
+__device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S, int r, int d, int sb, int t_next,
+                                             int &w, bool have_tail, double tail_dist, int tail_tmpl, int &has_new) {
+  int set = S.set[r];
+  int qb = N.spawn_ptr[set * N.n_lanes + d], qe = N.spawn_ptr[set * N.n_lanes + d + 1];
+  if (qb == qe) return;
+  int c = S.spawn_cur[IDX(d)];
+  if (qb + c >= qe) return;
+  int vbase = N.set_veh_ptr[set];
+  int vid = N.spawn_vid[qb + c];
+  if (N.veh_start[vbase + vid] > t_next) return;
+  int tid = tmpl_of<SINGLE>(N, vbase, vid);
+  if (have_tail) {
+    double tlen = N.tmpl[(size_t)tail_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+    double mg = N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
+    if (!(tail_dist > tlen + mg)) return;
+  }
+  if (w >= N.drv_cap[d]) {
+    atomicAdd(&S.errors[0], 1);
+    return;
+  }
+  int route = N.veh_route[vbase + vid];
+  int rb_ = N.route_ptr[route], re_ = N.route_ptr[route + 1];
+  S.dist[IDX(sb + w)] = 0;
+  S.speed[IDX(sb + w)] = 0;
+  S.tag[IDX(sb + w)] = TSC_MAKE_TAG(vid, 0);
+  S.aux[IDX(sb + w)] = (rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1;
+  S.blk[IDX(sb + w)] = -1;
+  S.blocker_by_vid[IDX(vid)] = -1;
+  S.spawn_cur[IDX(d)] = c + 1;
+  w++;
+  has_new = 1;
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, int n_rb, int n_dblk) {
+  int rb, dblk;
+  if (!map_block(n_rb, n_dblk, rb, dblk)) return;
+  int d = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (d >= N.n_drv || r >= S.R) return;
+  const bool is_link = d >= N.n_lanes;
+  const int sb = N.drv_slot_base[d];
+  const int cap = N.drv_cap[d];
+  const int t_now = S.t[r];
+  const int vbase = N.set_veh_ptr[S.set[r]];
+  int hdr = S.cnt[IDX(d)];
+  int n = hdr & TSC_CNT_MASK;
+  int tp = (hdr & TSC_NEW_BIT) ? -1 : S.tail_prev[IDX(d)];
+  // ---- keep / retire
+  int w = 0;
+  bool have_tail = false, old_tail_kept = false;
+  double tl_dist = 0, tl_speed = 0;
+  int tl_tag = 0;
+  for (int i = 0; i < n; i++) {
+    int fl = S.nflag[IDX(sb + i)];
+    if (fl == 0) {
+      double nd = S.ndist[IDX(sb + i)], ns = S.nspeed[IDX(sb + i)];
+      int tg = S.tag[IDX(sb + i)];
+      int ob_ = S.blk[IDX(sb + i)], nb = S.nblk[IDX(sb + i)];
+      S.dist[IDX(sb + w)] = nd;
+      S.speed[IDX(sb + w)] = ns;
+      if (w != i) {
+        S.tag[IDX(sb + w)] = tg;
+        S.aux[IDX(sb + w)] = S.aux[IDX(sb + i)];
+      }
+      S.blk[IDX(sb + w)] = nb;
+      if (ob_ != nb) S.blocker_by_vid[IDX(TSC_TAG_VID(tg))] = nb; // slot copy mirrors the vid-indexed entry
+      have_tail = true;
+      tl_dist = nd;
+      tl_speed = ns;
+      tl_tag = tg;
+      old_tail_kept = (i == n - 1);
+      w++;
+    } else if (fl & TSC_F_ENDED) {
+      int vid = TSC_TAG_VID(S.tag[IDX(sb + i)]);
+      int st0 = N.veh_start[vbase + vid];
+      atomicAdd(&S.fin_cnt[r], 1);
+      atomicAdd(&S.fin_dsum[r], (unsigned long long)(t_now - st0));
+      atomicAdd(&S.fin_ssum[r], (unsigned long long)st0);
+    }
+  }
+  if (!have_tail) tp = -1;
+  else if (!old_tail_kept) {
+    // the previous tail left while others stayed (overlap corner case): recover
+    // the new tail's previous drivable from its route
+    int vid = TSC_TAG_VID(tl_tag), seq = TSC_TAG_SEQ(tl_tag);
+    int route = N.veh_route[vbase + vid];
+    tp = seq > 0 ? N.route_drv[N.route_ptr[route] + seq - 1] : -1;
+  }
+  // ---- pull newcomers from feeder drivables, in descending buffered distance
+  int fb, fe;
+  if (is_link) {
+    fb = 0;
+    fe = 1;
+  } else {
+    fb = N.lane_in_ptr[d];
+    fe = N.lane_in_ptr[d + 1];
+  }
+  double last_nd = 1e300;
+  int last_vid = -1;
+  for (int pass = 0; pass < 16; pass++) {
+    double best_nd = -1e300;
+    int best_vid = 0x7fffffff, best_f = -1, best_s = -1, best_k = 0;
+    for (int q = fb; q < fe; q++) {
+      int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
+      int o = S.ob[IDX(f)];
+      int m = o & 3;
+      int fsb = N.drv_slot_base[f];
+      for (int k = 0; k < m; k++) {
+        int s = (o >> (2 + 10 * k)) & 1023;
+        size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
+        if (S.nflag[IDX(fsb + s)] & TSC_F_ENDED) continue;
+        if (is_link && S.obx_aux[ox] != d) continue;
+        double nd = S.ndist[IDX(fsb + s)];
+        int vid = TSC_TAG_VID(S.obx_tag[ox]);
+        bool after_last = nd < last_nd || (nd == last_nd && vid > last_vid);
+        bool before_best = nd > best_nd || (nd == best_nd && vid < best_vid);
+        if (after_last && before_best) {
+          best_nd = nd;
+          best_vid = vid;
+          best_f = f;
+          best_s = s;
+          best_k = k;
+        }
+      }
+    }
+    if (best_f < 0) break;
+    last_nd = best_nd;
+    last_vid = best_vid;
+    if (w >= cap) {
+      atomicAdd(&S.errors[0], 1);
+      break;
+    }
+    int fsb = N.drv_slot_base[best_f];
+    size_t box = ((size_t)best_f * TSC_OB_MAX + best_k) * (size_t)S.RS + (size_t)r;
+    int tg = S.obx_tag[box];
+    int seq = TSC_TAG_SEQ(tg) + 1;
+    int ob_ = S.obx_blk[box], nb = S.nblk[IDX(fsb + best_s)];
+    double ns = S.nspeed[IDX(fsb + best_s)];
+    int ntag = TSC_MAKE_TAG(best_vid, seq);
+    int naux;
+    if (is_link) {
+      naux = t_now; // enterLaneLinkTime
+    } else {
+      int route = N.veh_route[vbase + best_vid];
+      int pb = N.route_ptr[route], pe = N.route_ptr[route + 1];
+      naux = (pb + seq + 1 < pe) ? N.route_drv[pb + seq + 1] : -1;
+    }
+    S.dist[IDX(sb + w)] = best_nd;
+    S.speed[IDX(sb + w)] = ns;
+    S.tag[IDX(sb + w)] = ntag;
+    S.aux[IDX(sb + w)] = naux;
+    S.blk[IDX(sb + w)] = nb;
+    if (ob_ != nb) S.blocker_by_vid[IDX(best_vid)] = nb;
+    have_tail = true;
+    tl_dist = best_nd;
+    tl_speed = ns;
+    tl_tag = ntag;
+    tp = is_link ? -1 : best_f;
+    w++;
+  }
+  // ---- tail record (the tail BEFORE the next step's insertion)
+  if (have_tail) {
+    S.tail_dist[IDX(d)] = tl_dist;
+    S.tail_speed[IDX(d)] = tl_speed;
+    S.tail_tag[IDX(d)] = tl_tag;
+  }
+  S.tail_prev[IDX(d)] = tp;
+  // ---- spawn for the next step (engine: flows + handleWaiting, appendix B.3)
+  int has_new = 0;
+  if (!is_link) {
+    int tail_tmpl = have_tail ? tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tl_tag)) : 0;
+    spawn_if_due<SINGLE>(N, S, r, d, sb, t_now + 1, w, have_tail, tl_dist, tail_tmpl, has_new);
+  }
+  S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
+}
+
+// ----------------------------------------------------------------- k_reset
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_reset(DevNet N, DevState S, DevCfg C, const unsigned char *mask, int n_rb,
+                                               int n_dblk) {
+  int rb, dblk;
+  if (!map_block(n_rb, n_dblk, rb, dblk)) return;
+  int d = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (d >= N.n_drv || r >= S.R) return;
+  if (mask && !mask[r]) return;
+  // S.set / S.t were prepared by k_reset_replica (previous launch)
+  S.ob[IDX(d)] = 0;
+  S.tail_prev[IDX(d)] = -1;
+  int w = 0, has_new = 0;
+  if (d < N.n_lanes) {
+    S.spawn_cur[IDX(d)] = 0;
+    spawn_if_due<SINGLE>(N, S, r, d, N.drv_slot_base[d], 0, w, false, 0.0, 0, has_new);
+  }
+  S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
+}
+
+__global__ void k_reset_replica(DevNet N, DevState S, DevCfg C, const unsigned char *mask, int first) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.R) return;
+  if (mask && !mask[r]) return;
+  int restarts = first ? 0 : S.restarts[r] + (C.sequential_sets ? 1 : 0);
+  S.restarts[r] = restarts;
+  S.set[r] = (C.set_offset + r + restarts) % N.n_sets;
+  S.t[r] = -1;
+  S.fin_cnt[r] = 0;
+  S.fin_dsum[r] = 0;
+  S.fin_ssum[r] = 0;
+  for (int a = 0; a < N.n_agents; a++) {
+    S.cur_idx[IDX(a)] = 0;
+    S.top[IDX(a)] = 0;
+    S.changed[IDX(a)] = 0;
+    S.raw_phase[IDX(a)] = N.agent_phase_raw[a * TSC_MAX_AGENT_PHASES];
+  }
+}
+
+// ------------------------------------------------------------------ k_phase
+// action_space.apply -> switch_phase -> update_current_phase
+// (reference common/actions.py:99-108,144-158; common/traffic_signal.py:94-109)
+__global__ __launch_bounds__(256) void k_phase(DevNet N, DevState S, DevCfg C, const int *actions, int n_rb, int n_ablk) {
+  int rb, ablk;
+  if (!map_block(n_rb, n_ablk, rb, ablk)) return;
+  int a = __builtin_amdgcn_readfirstlane(ablk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (a >= N.n_agents || r >= S.R) return;
+  int act = actions[(size_t)r * N.n_agents + a];
+  int np_ = N.agent_n_phases[a];
+  int cur = S.cur_idx[IDX(a)];
+  int target;
+  if (C.action_space == TSC_ACT_PHASE_SWITCH) target = act == 1 ? (cur + 1) % np_ : cur;
+  else target = act;
+  if (target < 0 || target >= np_) {
+    atomicAdd(&S.errors[2], 1);
+    target = cur;
+  }
+  if (target == cur) {
+    S.changed[IDX(a)] = 0;
+    S.top[IDX(a)] += C.yellow_time;
+  } else {
+    S.changed[IDX(a)] = 1;
+    S.top[IDX(a)] = C.yellow_time;
+  }
+  S.cur_idx[IDX(a)] = target;
+  S.raw_phase[IDX(a)] = N.agent_phase_raw[a * TSC_MAX_AGENT_PHASES + target];
+}
+
+// ---------------------------------------------------------------- k_measure
+// std::to_string(double) -> float(): value rounded to 6 decimals
+__device__ __forceinline__ double round6(double x) {
+  double k = rint(x * 1e6);
+  double rr = fma(x, 1e6, -k);
+  if (rr > 0.5) k += 1.0;
+  else if (rr < -0.5) k -= 1.0;
+  return k / 1e6;
+}
+// CPython float floor division a // b for b > 0
+__device__ __forceinline__ double py_floordiv(double a, double b) {
+  double mod = fmod(a, b);
+  double div = (a - mod) / b;
+  if (mod != 0.0 && (mod < 0.0)) div -= 1.0;
+  double fl = floor(div);
+  if (div - fl > 0.5) fl += 1.0;
+  return fl;
+}
+
+#define MEASURE_WAVES 4
+#define MAX_VIS 16
+// Lane measurements (reference retriever.py:54-85, :20-52): counts, queue,
+// speed sum in list order, and the two visibility windows of the position
+// matrix binned in LDS (one private column per thread).
+__global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevState S, DevCfg C, int n_rb, int n_lblk) {
+  __shared__ double win[2 * MAX_VIS][MEASURE_WAVES][64];
+  int rb, lblk;
+  if (!map_block(n_rb, n_lblk, rb, lblk)) return;
+  int l = __builtin_amdgcn_readfirstlane(lblk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (l >= N.n_lanes || r >= S.R) return;
+  const int wy = threadIdx.y, lx = threadIdx.x;
+  const int vis = C.visibility;
+  int hdr = S.cnt[IDX(l)];
+  int n = (hdr & TSC_CNT_MASK) - ((hdr & TSC_NEW_BIT) ? 1 : 0);
+  const int sb = N.drv_slot_base[l];
+  const int bins = N.lane_bins[l];
+  const double len = N.lane_len_pytsc[l];
+  const double maxspd = N.drv_max_speed[l];
+  // padded matrix length and the two windows [-vis:] and [:vis]
+  const int plen = bins < vis ? vis : bins;
+  const int in0 = plen - vis;
+  for (int b = 0; b < 2 * vis; b++) win[b][wy][lx] = -1.0;
+  int q = 0;
+  double sum = 0;
+  double bin_size = bins > 0 ? len / bins : 1.0;
+  for (int i = 0; i < n; i++) {
+    double dist = S.dist[IDX(sb + i)];
+    double speed = S.speed[IDX(sb + i)];
+    if (speed < 0.1) q++;
+    sum += speed;
+    if (bins > 0) {
+      double pos = round6(dist);
+      if (pos < 0) pos = 0;
+      else if (pos > len) pos = len;
+      int idx = (int)py_floordiv(pos, bin_size);
+      if (idx >= bins) idx = bins - 1;
+      double norm_speed = round6(speed) / maxspd;
+      if (idx >= in0) {
+        double x = win[idx - in0][wy][lx];
+        x += 1.0;
+        x += norm_speed;
+        win[idx - in0][wy][lx] = x;
+      }
+      if (idx < vis) {
+        double x = win[vis + idx][wy][lx];
+        x += 1.0;
+        x += norm_speed;
+        win[vis + idx][wy][lx] = x;
+      }
+    }
+  }
+  // 3 predicate bits per incoming-window bin: occupied (>= 0), zero (== 0), >= 1
+  unsigned int ib = 0, obits = 0;
+  for (int b = 0; b < vis; b++) {
+    double x = win[b][wy][lx];
+    if (x >= 0.0) ib |= 1u << (3 * b);
+    if (x == 0.0) ib |= 2u << (3 * b);
+    if (x >= 1.0) ib |= 4u << (3 * b);
+    double y = win[vis + b][wy][lx];
+    if (y >= 0.0) obits |= 1u << b;
+  }
+  S.lane_n[IDX(l)] = n;
+  S.lane_q[IDX(l)] = q;
+  S.lane_sum[IDX(l)] = sum;
+  S.lane_in_bits[IDX(l)] = ib;
+  S.lane_out_bits[IDX(l)] = obits;
+}
+
+// Full position matrices for the single-replica facade / parity checks.
+__global__ void k_posmat(DevNet N, DevState S, DevCfg C, double *posmat, int max_bins, int n_rb, int n_lblk) {
+  int rb, lblk;
+  if (!map_block(n_rb, n_lblk, rb, lblk)) return;
+  int l = lblk * (int)blockDim.y + (int)threadIdx.y;
+  int r = rb * 64 + threadIdx.x;
+  if (l >= N.n_lanes || r >= S.R) return;
+  int hdr = S.cnt[IDX(l)];
+  int n = (hdr & TSC_CNT_MASK) - ((hdr & TSC_NEW_BIT) ? 1 : 0);
+  const int sb = N.drv_slot_base[l];
+  const int bins = N.lane_bins[l];
+  const double len = N.lane_len_pytsc[l];
+  const double maxspd = N.drv_max_speed[l];
+  double *pm = posmat + ((size_t)r * N.n_lanes + l) * max_bins;
+  for (int b = 0; b < max_bins; b++) pm[b] = -1.0;
+  if (bins <= 0) return;
+  double bin_size = len / bins;
+  for (int i = 0; i < n; i++) {
+    double pos = round6(S.dist[IDX(sb + i)]);
+    if (pos < 0) pos = 0;
+    else if (pos > len) pos = len;
+    int idx = (int)py_floordiv(pos, bin_size);
+    if (idx >= bins) idx = bins - 1;
+    double norm_speed = round6(S.speed[IDX(sb + i)]) / maxspd;
+    pm[idx] += 1.0;
+    pm[idx] += norm_speed;
+  }
+}
+
+__global__ void k_lane_detail(DevNet N, DevState S, int *lane_counts, double *lane_speed, int n_rb, int n_lblk) {
+  int rb, lblk;
+  if (!map_block(n_rb, n_lblk, rb, lblk)) return;
+  int l = lblk * (int)blockDim.y + (int)threadIdx.y;
+  int r = rb * 64 + threadIdx.x;
+  if (l >= N.n_lanes || r >= S.R) return;
+  lane_counts[((size_t)r * N.n_lanes + l) * 2 + 0] = S.lane_n[IDX(l)];
+  lane_counts[((size_t)r * N.n_lanes + l) * 2 + 1] = S.lane_q[IDX(l)];
+  lane_speed[(size_t)r * N.n_lanes + l] = S.lane_sum[IDX(l)];
+}
+
+// ------------------------------------------------------------------ k_agent
+__device__ __forceinline__ double lane_mean_speed(const DevState &S, int r, int l) {
+  int n = S.lane_n[IDX(l)];
+  return n == 0 ? 0.0 : S.lane_sum[IDX(l)] / n;
+}
+__device__ __forceinline__ double lane_occupancy(const DevNet &N, const DevState &S, const DevCfg &C, int r, int l) {
+  double lane_length = N.lane_len_pytsc[l] / C.veh_size_min_gap;
+  return S.lane_n[IDX(l)] / lane_length;
+}
+
+#define AGENT_WAVES 2
+// Per-agent statistics, observation / state vectors, action mask (reference
+// backends/cityflow/traffic_signal.py:101-141, common/observations.py:140-160,
+// 183-205, common/actions.py:119-131,169-188, common/traffic_signal.py:329-404).
+// Rows are assembled in LDS (one row per replica of the wave) and streamed out
+// so that the [R, A, obs] stores are contiguous 256-byte segments.
+__global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S, DevCfg C, tsc_step_out_t out,
+                                                            int row_stride, int n_rb, int n_ablk) {
+  extern __shared__ unsigned char rows_lds[]; // [AGENT_WAVES][64][row_stride], values stored +1
+  int rb, ablk;
+  bool live = map_block(n_rb, n_ablk, rb, ablk);
+  int a = __builtin_amdgcn_readfirstlane(ablk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  const int wy = threadIdx.y, lx = threadIdx.x;
+  live = live && a < N.n_agents;
+  const bool mine = live && r < S.R;
+  const int A = N.n_agents, vis = C.visibility;
+  int cur = 0, np_ = 1;
+  if (mine) {
+    int ib = N.agent_inc_ptr[a], ie = N.agent_inc_ptr[a + 1];
+    int ob = N.agent_out_ptr[a], oe = N.agent_out_ptr[a + 1];
+    int nq = 0;
+    double occ = 0, ms = 0, md = 0;
+    for (int k = ib; k < ie; k++) {
+      int l = N.agent_inc_lanes[k];
+      nq += S.lane_q[IDX(l)];
+      occ += lane_occupancy(N, S, C, r, l);
+      double m = lane_mean_speed(S, r, l);
+      ms += m;
+      md += 1 - m / N.drv_max_speed[l];
+    }
+    occ /= (ie - ib);
+    ms /= (ie - ib);
+    md /= (ie - ib);
+    double oocc = 0;
+    for (int k = ob; k < oe; k++) oocc += lane_occupancy(N, S, C, r, N.agent_out_lanes[k]);
+    oocc /= (oe - ob);
+    double pressure = fabs(occ - oocc);
+    cur = S.cur_idx[IDX(a)];
+    np_ = N.agent_n_phases[a];
+    int top = S.top[IDX(a)];
+    int changed = S.changed[IDX(a)];
+    double pc = changed ? 1.0 : 0.0;
+    double local;
+    if (C.reward_kind == 0) local = -C.flickering_coef * pc - nq - 1e-6;
+    else local = -C.flickering_coef * pc - pressure - 1e-6;
+    S.agent_local[IDX(a)] = local;
+    S.agent_pressure[IDX(a)] = pressure;
+    if (out.agent_stats_dev) {
+      double *s = out.agent_stats_dev + ((size_t)r * A + a) * TSC_N_AGENT_STATS;
+      int sim_step = (S.t[r] + 1) - C.initial_wait_time;
+      s[TSC_A_N_QUEUED] = nq;
+      s[TSC_A_OCCUPANCY] = occ;
+      s[TSC_A_MEAN_SPEED] = ms;
+      s[TSC_A_MEAN_DELAY] = md;
+      s[TSC_A_OUT_OCCUPANCY] = oocc;
+      s[TSC_A_PRESSURE] = pressure;
+      s[TSC_A_NORM_TIME_ON_PHASE] = (double)top / (double)N.agent_phase_max[a * TSC_MAX_AGENT_PHASES + cur];
+      s[TSC_A_SIM_STEP_NORM] = sim_step / 3600.0;
+    }
+    if (out.phase_dev) {
+      int *p = out.phase_dev + ((size_t)r * A + a) * 3;
+      p[0] = cur;
+      p[1] = top;
+      p[2] = changed;
+    }
+    if (out.mask_dev) {
+      const int *green = N.agent_phase_green + a * TSC_MAX_AGENT_PHASES;
+      int nxt = (cur + 1) % np_;
+      unsigned int m = 0;
+      if (green[cur]) {
+        int mn = N.agent_phase_min[a * TSC_MAX_AGENT_PHASES + cur];
+        int mx = N.agent_phase_max[a * TSC_MAX_AGENT_PHASES + cur];
+        if (top < mn) m = 1u << cur;
+        else if (top < mx) m = (1u << cur) | (1u << nxt);
+        else if (top == mx) m = 1u << nxt;
+      } else if (C.round_robin) {
+        m = 1u << nxt;
+      } else {
+        for (int i = 0; i < np_; i++)
+          if (green[i] && i != cur - 1) m |= 1u << i;
+      }
+      unsigned char *mk = out.mask_dev + ((size_t)r * A + a) * C.n_actions;
+      if (C.action_space == TSC_ACT_PHASE_SWITCH) {
+        mk[0] = (m >> cur) & 1u;
+        mk[1] = (m >> nxt) & 1u;
+      } else {
+        for (int i = 0; i < C.n_actions; i++) mk[i] = (i < np_) ? ((m >> i) & 1u) : 0;
+      }
+    }
+  }
+  // ---- observation rows (Q1 integer truncation, Q2 compaction)
+  if (out.obs_dev) {
+    if (mine) {
+      unsigned char *row = rows_lds + ((size_t)wy * 64 + lx) * row_stride;
+      int w = 0;
+      for (int k = N.agent_inc_ptr[a]; k < N.agent_inc_ptr[a + 1]; k++) {
+        int l = N.agent_inc_lanes[k];
+        for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
+        unsigned int bits = S.lane_in_bits[IDX(l)];
+        for (int b = 0; b < vis; b++) {
+          unsigned int t3 = (bits >> (3 * b)) & 7u;
+          // kept iff value > 0: occupied and not exactly zero; value = trunc(clip(v, 0, 1))
+          if ((t3 & 1u) && !(t3 & 2u)) row[w++] = (t3 & 4u) ? 2 : 1;
+        }
+      }
+      int body = C.obs_size - TSC_MAX_PHASES;
+      for (; w < body; w++) row[w] = 0;
+      for (int i = 0; i < TSC_MAX_PHASES; i++) row[w++] = i < np_ ? (i == cur ? 2 : 1) : 0;
+    }
+    __syncthreads();
+    if (live) {
+      for (int rr = 0; rr < 64; rr++) {
+        int r2 = rb * 64 + rr;
+        if (r2 >= S.R) break;
+        float *dst = out.obs_dev + ((size_t)r2 * A + a) * C.obs_size;
+        const unsigned char *src = rows_lds + ((size_t)wy * 64 + rr) * row_stride;
+        for (int j = lx; j < C.obs_size; j += 64) dst[j] = (float)((int)src[j] - 1);
+      }
+    }
+    __syncthreads();
+  }
+  if (out.state_dev) {
+    if (mine) {
+      unsigned char *row = rows_lds + ((size_t)wy * 64 + lx) * row_stride;
+      int w = 0;
+      for (int k = N.agent_inc_ptr[a]; k < N.agent_inc_ptr[a + 1]; k++) {
+        int l = N.agent_inc_lanes[k];
+        for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
+        row[w++] = (unsigned char)(S.lane_q[IDX(l)] + 1);
+        row[w++] = (unsigned char)((int)(long long)lane_occupancy(N, S, C, r, l) + 1);
+        row[w++] = (unsigned char)((int)(long long)lane_mean_speed(S, r, l) + 1);
+      }
+      int body = C.state_size - TSC_MAX_PHASES;
+      for (; w < body; w++) row[w] = 0;
+      for (int i = 0; i < TSC_MAX_PHASES; i++) row[w++] = (i < np_ && i == cur) ? 2 : 1;
+    }
+    __syncthreads();
+    if (live) {
+      for (int rr = 0; rr < 64; rr++) {
+        int r2 = rb * 64 + rr;
+        if (r2 >= S.R) break;
+        float *dst = out.state_dev + ((size_t)r2 * A + a) * C.state_size;
+        const unsigned char *src = rows_lds + ((size_t)wy * 64 + rr) * row_stride;
+        for (int j = lx; j < C.state_size; j += 64) dst[j] = (float)((int)src[j] - 1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_stats
+__device__ double np_pairwise_sum_col(const double *a, size_t stride, int n) {
+  // numpy add.reduce on a contiguous f64 array (n <= 128 path and recursion)
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; i++) res += a[(size_t)i * stride];
+    return res;
+  } else if (n <= 128) {
+    double r0 = a[0], r1 = a[stride], r2 = a[2 * stride], r3 = a[3 * stride], r4 = a[4 * stride],
+           r5 = a[5 * stride], r6 = a[6 * stride], r7 = a[7 * stride];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+      r0 += a[(size_t)(i + 0) * stride];
+      r1 += a[(size_t)(i + 1) * stride];
+      r2 += a[(size_t)(i + 2) * stride];
+      r3 += a[(size_t)(i + 3) * stride];
+      r4 += a[(size_t)(i + 4) * stride];
+      r5 += a[(size_t)(i + 5) * stride];
+      r6 += a[(size_t)(i + 6) * stride];
+      r7 += a[(size_t)(i + 7) * stride];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[(size_t)i * stride];
+    return res;
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_col(a, stride, n2) + np_pairwise_sum_col(a + (size_t)n2 * stride, stride, n - n2);
+  }
+}
+
+// Network metrics, rewards, episode flags (reference backends/cityflow/metrics.py:24-260,
+// common/reward.py:54-88,106-136, pytsc/__init__.py:58-62, simulator.py:20-30).
+__global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.R) return;
+  const int A = N.n_agents;
+  long long nq_all = 0, nveh_all = 0;
+  double dens = 0, nms = 0, tvs = 0;
+  for (int l = 0; l < N.n_lanes; l++) {
+    int n = S.lane_n[IDX(l)];
+    nq_all += S.lane_q[IDX(l)];
+    nveh_all += n;
+    dens += lane_occupancy(N, S, C, r, l);
+    double m = n == 0 ? 0.0 : S.lane_sum[IDX(l)] / n;
+    nms += m / N.drv_max_speed[l];
+    tvs += m * n;
+  }
+  double density = dens / N.n_lanes;
+  double norm_mean_speed = nms / N.n_lanes;
+  double mean_speed = nveh_all == 0 ? 0.0 : tvs / (double)nveh_all;
+  double pressure = np_pairwise_sum_col(S.agent_pressure + r, (size_t)S.RS, A);
+  int n_changed = 0;
+  for (int a = 0; a < A; a++) n_changed += S.changed[IDX(a)] ? 1 : 0;
+  double flick = (double)n_changed / (double)A;
+  double g;
+  if (C.reward_kind == 0) {
+    g = 1e-6;
+    g += C.flickering_coef * flick;
+    g += (double)nq_all;
+    g = -1 * g;
+  } else {
+    g = 1e-6;
+    g -= C.flickering_coef * flick;
+    g -= pressure;
+  }
+  if (out.global_reward_dev) out.global_reward_dev[r] = (float)g;
+  if (out.global_reward64_dev) out.global_reward64_dev[r] = g;
+  if (out.local_reward_dev || out.local_reward64_dev) {
+    for (int a = 0; a < A; a++) {
+      double rew = S.agent_local[IDX(a)];
+      for (int k = N.agent_nbr_ptr[a]; k < N.agent_nbr_ptr[a + 1]; k++)
+        rew += N.agent_nbr_w[k] * S.agent_local[IDX(N.agent_nbr[k])];
+      if (out.local_reward_dev) out.local_reward_dev[(size_t)r * A + a] = (float)rew;
+      if (out.local_reward64_dev) out.local_reward64_dev[(size_t)r * A + a] = rew;
+    }
+  }
+  int step = S.t[r] + 1; // engine steps completed
+  int sim_step = step - C.initial_wait_time;
+  if (out.stats_dev) {
+    double now = step * C.interval;
+    // finished durations + (now - creation time) of every created, unfinished vehicle
+    int set = S.set[r];
+    int tt_i = step < N.sim_len + 1 ? step : N.sim_len + 1;
+    long long created = N.created_cnt[(size_t)set * (N.sim_len + 2) + tt_i];
+    long long created_ts = N.created_tsum[(size_t)set * (N.sim_len + 2) + tt_i];
+    long long fin = S.fin_cnt[r];
+    long long fin_dur = (long long)S.fin_dsum[r];   // sum of (finish step - creation step)
+    long long fin_start = (long long)S.fin_ssum[r]; // sum of creation steps of finished vehicles
+    // pooled = created, unfinished (waiting included); sum over them of (now - creation time).
+    // With interval == 1 every term is an integer, so this equals the engine's f64 loop exactly.
+    long long pooled = created - fin;
+    long long pooled_wait = pooled * (long long)step - (created_ts - fin_start);
+    long long n_all = fin + pooled;
+    double avg = n_all == 0 ? 0.0 : ((double)fin_dur * C.interval + (double)pooled_wait * C.interval) / (double)n_all;
+    double *s = out.stats_dev + (size_t)r * TSC_N_STATS;
+    s[TSC_S_TIME_STEP] = now;
+    s[TSC_S_AVG_TRAVEL_TIME] = avg;
+    s[TSC_S_N_QUEUED] = (double)nq_all;
+    s[TSC_S_MEAN_SPEED] = mean_speed;
+    s[TSC_S_MEAN_DELAY] = 1 - norm_mean_speed;
+    s[TSC_S_DENSITY] = density;
+    s[TSC_S_PRESSURE] = pressure;
+    s[TSC_S_NETWORK_FLOW] = density * norm_mean_speed;
+  }
+  if (out.done_dev) out.done_dev[r] = (unsigned char)(sim_step > 0 && sim_step % C.episode_limit == 0);
+  if (out.terminated_dev) out.terminated_dev[r] = (unsigned char)(sim_step == C.sim_length);
+}
+
+// --------------------------------------------------------------- k_snapshot
+__global__ void k_snapshot(DevNet N, DevState S, int rep, int cap, int *count, int *drv, int *slot, double *dist,
+                           double *speed, int *vid) {
+  int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= N.n_drv) return;
+  int r = rep;
+  int hdr = S.cnt[IDX(d)];
+  int n = (hdr & TSC_CNT_MASK) - ((hdr & TSC_NEW_BIT) ? 1 : 0);
+  int sb = N.drv_slot_base[d];
+  for (int i = 0; i < n; i++) {
+    int k = atomicAdd(count, 1);
+    if (k < cap) {
+      drv[k] = d;
+      slot[k] = i;
+      dist[k] = S.dist[IDX(sb + i)];
+      speed[k] = S.speed[IDX(sb + i)];
+      vid[k] = TSC_TAG_VID(S.tag[IDX(sb + i)]);
+    }
+  }
+}
+
+__global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.R) return;
+  unsigned long long c = 0;
+  for (int d = 0; d < N.n_drv; d++) {
+    int hdr = S.cnt[IDX(d)];
+    c += (hdr & TSC_CNT_MASK) - ((hdr & TSC_NEW_BIT) ? 1 : 0);
+  }
+  atomicAdd(total, c);
+}
+
+#include "tsc_api.inc"

@@ -1,0 +1,302 @@
+"""Flow JSON -> per-vehicle spawn schedule + static drivable routes; demand generators.
+
+On-disk format: the reference's CityFlow flow files (SURVEY.md appendix C;
+producer pytsc/backends/cityflow/trip_generator.py:252-287): a list of
+``{vehicle{...}, route[road ids], interval, startTime, endTime}``.
+
+A vehicle's path through drivables (lane, lane-link, lane, ..., lane) is a pure
+function of its road route on these networks, so it is resolved here once
+(first lane = a lane of route[0] linked to route[1];
+next lane-link = closest end-lane index that still connects to the road after
+next) and the device only carries (route id, position in route).
+"""
+import json
+
+import numpy as np
+
+TMPL_KEYS = (
+    "length",
+    "width",
+    "maxPosAcc",
+    "maxNegAcc",
+    "usualPosAcc",
+    "usualNegAcc",
+    "minGap",
+    "maxSpeed",
+    "headwayTime",
+)
+DEFAULT_YIELD_DISTANCE = 5.0
+DEFAULT_TURN_SPEED = 8.3333
+
+DEFAULT_VEHICLE = {  # reference template: trip_generator.py:47-57
+    "length": 5.0,
+    "width": 2.0,
+    "maxPosAcc": 2.0,
+    "maxNegAcc": 4.5,
+    "usualPosAcc": 2.0,
+    "usualNegAcc": 4.5,
+    "minGap": 2.5,
+    "maxSpeed": 11.11,
+    "headwayTime": 1.5,
+}
+
+
+def load_flow_file(path):
+    with open(path, "r") as f:
+        return json.load(f)
+
+
+def template_vector(veh, interval):
+    v = [float(veh[k]) for k in TMPL_KEYS]
+    v.append(float(veh.get("yieldDistance", DEFAULT_YIELD_DISTANCE)))
+    v.append(float(veh.get("turnSpeed", DEFAULT_TURN_SPEED)))
+    max_speed, usual_neg = v[7], v[5]
+    v.append(max_speed * max_speed / usual_neg / 2 + max_speed * interval * 2)
+    return tuple(v)
+
+
+def _select_link(rn, cur_lane, links):
+    """Closest end-lane index to the current lane index (first minimum)."""
+    best, best_diff = None, None
+    ci = int(rn.lane_idx_in_road[cur_lane])
+    for l in links:
+        d = abs(int(rn.lane_idx_in_road[rn.links[l]["end"]]) - ci)
+        if best_diff is None or d < best_diff:
+            best, best_diff = l, d
+    return best
+
+
+def route_to_drivables(rn, roads):
+    """Road-id route -> [lane, link, lane, ...] drivable indices, or None if
+    the route is not drivable (the engine drops such vehicles)."""
+    for r in roads:
+        if r not in rn.road_by_id:
+            return None
+    first_lanes = rn.road_lanes(roads[0])
+    if len(roads) == 1:
+        cur = first_lanes[0]
+    else:
+        cands = [l for l in first_lanes if rn.links_to_road(l, roads[1])]
+        if not cands:
+            return None
+        # the engine draws uniformly among candidates; every shipped network has
+        # exactly one (left / straight / right lanes), we take the first
+        cur = cands[0]
+    seq = [cur]
+    n = len(roads)
+    for i in range(n - 1):
+        links = rn.links_to_road(cur, roads[i + 1])
+        if i == n - 2:
+            sel = _select_link(rn, cur, links)
+        else:
+            sel = None
+            cand = list(links)
+            while cand:
+                s = _select_link(rn, cur, cand)
+                if rn.links_to_road(rn.links[s]["end"], roads[i + 2]):
+                    sel = s
+                    break
+                cand.remove(s)
+        if sel is None:
+            return None
+        cur = rn.links[sel]["end"]
+        seq.append(rn.n_lanes + sel)
+        seq.append(cur)
+    return seq
+
+
+class FlowSet:
+    """One demand file expanded to vehicles, sorted in creation order."""
+
+    def __init__(self, veh_route, veh_start, veh_tmpl):
+        self.veh_route = np.asarray(veh_route, dtype=np.int32)
+        self.veh_start = np.asarray(veh_start, dtype=np.int32)
+        self.veh_tmpl = np.asarray(veh_tmpl, dtype=np.int32)
+
+    @property
+    def n_veh(self):
+        return len(self.veh_route)
+
+
+class FlowCompiler:
+    """Accumulates routes/templates across flow sets of one network."""
+
+    def __init__(self, rn, interval=1.0):
+        self.rn = rn
+        self.interval = float(interval)
+        self.routes = []
+        self.route_index = {}
+        self.tmpls = []
+        self.tmpl_index = {}
+        self.sets = []
+
+    def _route_id(self, roads):
+        key = tuple(roads)
+        if key not in self.route_index:
+            seq = route_to_drivables(self.rn, roads)
+            if seq is None:
+                self.route_index[key] = -1
+            else:
+                self.route_index[key] = len(self.routes)
+                self.routes.append(seq)
+        return self.route_index[key]
+
+    def _tmpl_id(self, veh):
+        key = template_vector(veh, self.interval)
+        if key not in self.tmpl_index:
+            self.tmpl_index[key] = len(self.tmpls)
+            self.tmpls.append(key)
+        return self.tmpl_index[key]
+
+    def add(self, entries, sim_len):
+        """Expand flow entries to vehicles created at engine steps < sim_len.
+
+        Per entry: a counter `now` starts at
+        `interval`; at each step with startTime <= t (<= endTime unless -1),
+        while now >= interval a vehicle is created and now -= interval; then
+        now += dt.  Vehicles of one step are ordered by entry index.
+        """
+        dt = self.interval
+        per_step = []
+        for fi, e in enumerate(entries):
+            rid = self._route_id(e["route"])
+            if rid < 0:
+                continue  # invalid route: flow is disabled by the engine
+            tid = self._tmpl_id(e["vehicle"])
+            start = e["startTime"]
+            end = e["endTime"]
+            ivl = float(e["interval"])
+            now = ivl
+            # engine time at step s is s*dt; the flow keeps its own clock
+            s = 0
+            cur = 0.0
+            cnt = 0
+            # fast path: single-shot entries (all shipped files)
+            if end == start and ivl >= dt and float(start) == int(start) and dt == 1.0:
+                if start < sim_len:
+                    per_step.append((int(start), fi, 0, rid, tid))
+                continue
+            while s < sim_len:
+                if end != -1 and cur > end:
+                    break
+                if cur >= start:
+                    while now >= ivl:
+                        per_step.append((s, fi, cnt, rid, tid))
+                        cnt += 1
+                        now -= ivl
+                    now += dt
+                cur += dt
+                s += 1
+        per_step.sort(key=lambda t: (t[0], t[1], t[2]))
+        fs = FlowSet(
+            [t[3] for t in per_step], [t[0] for t in per_step], [t[4] for t in per_step]
+        )
+        self.sets.append(fs)
+        return fs
+
+
+# --------------------------------------------------------------------------
+# generators (reference format; SURVEY.md §8(d) config 2: Poisson arrivals)
+# --------------------------------------------------------------------------
+def fringe_roads(rn):
+    """(incoming, outgoing) boundary roads (trip_generator.py:150-180)."""
+    inc, out = [], []
+    for road in rn.roads:
+        sv = rn.inter_by_id[road["startIntersection"]]["virtual"]
+        ev = rn.inter_by_id[road["endIntersection"]]["virtual"]
+        if sv and not ev:
+            inc.append(road["id"])
+        if ev and not sv:
+            out.append(road["id"])
+    return inc, out
+
+
+def _road_turns(rn):
+    conn = {}
+    for it in rn.intersections:
+        for rl in it.get("roadLinks", []):
+            conn.setdefault(rl["startRoad"], {})[rl["type"]] = rl["endRoad"]
+    return conn
+
+
+def random_walk_route(rn, conn, out_set, start_road, rng, turn_probs, max_len):
+    """Random-walk route in the spirit of trip_generator.py:200-249: weighted
+    turn choice, no road twice, stop at a boundary-out road or a dead end."""
+    turns = ("turn_left", "turn_right", "go_straight")
+    while True:
+        route = [start_road]
+        cur = start_road
+        while True:
+            cands, w = [], []
+            for i, t in enumerate(turns):
+                nxt = conn.get(cur, {}).get(t)
+                if nxt is not None and nxt not in route:
+                    cands.append(nxt)
+                    w.append(turn_probs[i])
+            if not cands or sum(w) == 0:
+                break
+            w = np.asarray(w) / sum(w)
+            nxt = cands[int(rng.choice(len(cands), p=w))]
+            route.append(nxt)
+            cur = nxt
+            if nxt in out_set:
+                break
+        if 1 < len(route) <= max_len:
+            return route
+
+
+def poisson_flows(rn, rate_veh_per_hour=700.0, horizon=3600, seed=0,
+                  turn_probs=(0.1, 0.3, 0.6), vehicle=None, max_len=None):
+    """Poisson demand: exponential inter-arrival times (mean 3600/rate s) on
+    every boundary-in road, integer start second, random-walk routes."""
+    rng = np.random.default_rng(seed)
+    vehicle = dict(DEFAULT_VEHICLE if vehicle is None else vehicle)
+    inc, out = fringe_roads(rn)
+    conn = _road_turns(rn)
+    out_set = set(out)
+    if max_len is None:
+        max_len = rn.n_agents + 2
+    mean = 3600.0 / rate_veh_per_hour
+    flows = []
+    for road in inc:
+        t = 0.0
+        while True:
+            t += rng.exponential(mean)
+            if t >= horizon:
+                break
+            route = random_walk_route(rn, conn, out_set, road, rng, turn_probs, max_len)
+            st = int(t)
+            flows.append(
+                {"vehicle": vehicle, "route": route, "interval": 1.0,
+                 "startTime": st, "endTime": st}
+            )
+    flows.sort(key=lambda e: e["startTime"])
+    return flows
+
+
+# --------------------------------------------------------------------------
+# compact on-disk form of a flow file (fixtures / generated scenarios)
+# --------------------------------------------------------------------------
+def compact_flows(entries):
+    """{vehicles, routes, entries[[veh, route, start, end, interval]]}: the same
+    information as the flow JSON with the repeated objects factored out."""
+    vehicles, vidx, routes, ridx, rows = [], {}, [], {}, []
+    for e in entries:
+        vk = json.dumps(e["vehicle"], sort_keys=True)
+        if vk not in vidx:
+            vidx[vk] = len(vehicles)
+            vehicles.append(e["vehicle"])
+        rk = tuple(e["route"])
+        if rk not in ridx:
+            ridx[rk] = len(routes)
+            routes.append(list(e["route"]))
+        rows.append([vidx[vk], ridx[rk], e["startTime"], e["endTime"], e["interval"]])
+    return {"vehicles": vehicles, "routes": routes, "entries": rows}
+
+
+def expand_flows(compact):
+    return [
+        {"vehicle": compact["vehicles"][v], "route": compact["routes"][r],
+         "interval": ivl, "startTime": st, "endTime": en}
+        for v, r, st, en, ivl in compact["entries"]
+    ]

@@ -1,0 +1,52 @@
+"""Scenario assembly: Config -> RoadNet -> NetworkParser -> flow sets -> Tables."""
+import os
+
+from pytsc_amd.flows import FlowCompiler, load_flow_file, poisson_flows
+from pytsc_amd.grid import generate_grid
+from pytsc_amd.network_parser import NetworkParser
+from pytsc_amd.roadnet import RoadNet
+from pytsc_amd.tables import Tables
+
+
+def load_roadnet(config):
+    if "roadnet_json" in config.simulator:
+        return RoadNet(config.simulator["roadnet_json"])
+    if config.synthetic_grid is not None:
+        rows, cols = config.synthetic_grid
+        return RoadNet(generate_grid(rows, cols))
+    return RoadNet.from_file(config.roadnet_file)
+
+
+def flow_entry_sets(config, rn):
+    """List of flow-entry lists: the scenario's flow file(s), or synthetic
+    Poisson demand for syn_RxC scenarios."""
+    sim = config.simulator
+    if "flow_entries" in sim:  # in-memory demand (tests, bench)
+        return list(sim["flow_entries"])
+    files = []
+    kind = sim.get("flow_rate_type", "constant")
+    if kind == "constant" and sim.get("flow_file"):
+        files = [sim["flow_file"]]
+    elif sim.get("flow_files"):
+        files = list(sim["flow_files"])
+    elif sim.get("flow_file"):
+        files = [sim["flow_file"]]
+    if files:
+        return [load_flow_file(os.path.join(config.dir, f)) for f in files]
+    n_sets = int(sim.get("n_flow_sets", 1))
+    rate = float(sim.get("flow_rate", 700.0))
+    horizon = int(sim["sim_length"]) + int(sim["initial_wait_time"])
+    seed = int(sim.get("flow_seed", sim["seed"]))
+    return [poisson_flows(rn, rate, horizon, seed=seed + i) for i in range(n_sets)]
+
+
+def build_tables(config, n_replicas=None, roadnet=None, set_offset=0):
+    rn = roadnet if roadnet is not None else load_roadnet(config)
+    parser = NetworkParser(config, roadnet=rn)
+    fc = FlowCompiler(rn, interval=float(config.simulator["interval"]))
+    horizon = int(config.simulator["sim_length"]) + int(config.simulator["initial_wait_time"])
+    for entries in flow_entry_sets(config, rn):
+        fc.add(entries, horizon)
+    if n_replicas is None:
+        n_replicas = int(config.simulator.get("n_replicas", 1))
+    return Tables(parser, fc, config, n_replicas, set_offset=set_offset)

@@ -1,0 +1,129 @@
+"""Batched environment: R replicas of one signalised network stepped together on
+one MI355X through the C-ABI (include/pytsc_amd.h).  Outputs are torch tensors
+that live in HBM; nothing on the step path touches the host.
+
+API mirrors the reference façade (pytsc/__init__.py:17-182) with a leading
+replica axis: step(actions[R, A]) -> (global_reward[R], done[R], stats[R, 8]),
+get_observations() -> [R, A, obs], get_state(), get_rewards(), get_action_mask().
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from pytsc_amd import _lib
+from pytsc_amd.tables import N_AGENT_STATS, N_STATS, TscStepOut
+
+STAT_KEYS = ("time_step", "average_travel_time", "n_queued", "mean_speed", "mean_delay",
+             "density", "pressure", "network_flow")
+
+
+class VecEngine:
+    """Thin owner of a tsc_handle_t plus its caller-owned device output buffers."""
+
+    def __init__(self, tables, device=0, want=("obs", "state", "mask", "local_reward", "global_reward",
+                                              "done", "terminated", "stats", "agent_stats", "phase",
+                                              "local_reward64", "global_reward64")):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pytsc_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.tables = tables
+        self.device = torch.device("cuda", device)
+        self.R, self.A = tables.n_replicas, tables.n_agents
+        h = C.c_void_p()
+        _lib.check(self.lib.tsc_create(C.byref(tables.net), C.byref(tables.flows), C.byref(tables.cfg),
+                                       device, C.byref(h)), "tsc_create")
+        self.h = h
+        self.n_actions = self.lib.tsc_n_actions(h)
+        self.obs_size = self.lib.tsc_obs_size(h)
+        self.state_size = self.lib.tsc_state_size(h)
+        R, A, dev = self.R, self.A, self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        shapes = {
+            "obs": ((R, A, self.obs_size), torch.float32),
+            "state": ((R, A, self.state_size), torch.float32),
+            "mask": ((R, A, self.n_actions), torch.uint8),
+            "local_reward": ((R, A), torch.float32),
+            "global_reward": ((R,), torch.float32),
+            "done": ((R,), torch.uint8),
+            "terminated": ((R,), torch.uint8),
+            "stats": ((R, N_STATS), torch.float64),
+            "agent_stats": ((R, A, N_AGENT_STATS), torch.float64),
+            "phase": ((R, A, 3), torch.int32),
+            "local_reward64": ((R, A), torch.float64),
+            "global_reward64": ((R,), torch.float64),
+        }
+        self.buf = {k: z(*shapes[k]) for k in want}
+        ptr = lambda k: self.buf[k].data_ptr() if k in self.buf else None
+        self.out = TscStepOut(ptr("obs"), ptr("state"), ptr("mask"), ptr("local_reward"),
+                              ptr("global_reward"), ptr("done"), ptr("terminated"), ptr("stats"),
+                              ptr("agent_stats"), ptr("phase"), ptr("local_reward64"),
+                              ptr("global_reward64"))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            m = C.c_void_p(mask.data_ptr())
+        _lib.check(self.lib.tsc_reset(self.h, m, self._stream()), "tsc_reset")
+
+    def observe(self):
+        _lib.check(self.lib.tsc_observe(self.h, C.byref(self.out), self._stream()), "tsc_observe")
+        return self.buf
+
+    def step(self, actions):
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if actions.shape != (self.R, self.A):
+            raise ValueError(f"actions must be [{self.R}, {self.A}]")
+        self._last_actions = actions  # keep alive until the kernels have run
+        _lib.check(self.lib.tsc_step(self.h, C.c_void_p(actions.data_ptr()), C.byref(self.out),
+                                     self._stream()), "tsc_step")
+        return self.buf
+
+    def lane_detail(self, with_posmat=False):
+        R, nl, mb = self.R, self.tables.n_lanes, self.tables.max_bins
+        counts = torch.zeros((R, nl, 2), dtype=torch.int32, device=self.device)
+        speed = torch.zeros((R, nl), dtype=torch.float64, device=self.device)
+        pm = torch.zeros((R, nl, mb), dtype=torch.float64, device=self.device) if with_posmat else None
+        _lib.check(self.lib.tsc_lane_detail(self.h, C.c_void_p(counts.data_ptr()),
+                                            C.c_void_p(speed.data_ptr()),
+                                            C.c_void_p(pm.data_ptr()) if with_posmat else None, mb,
+                                            self._stream()), "tsc_lane_detail")
+        return counts, speed, pm
+
+    def snapshot(self, rep=0, cap=65536):
+        drv = np.zeros(cap, np.int32)
+        dist = np.zeros(cap, np.float64)
+        speed = np.zeros(cap, np.float64)
+        vid = np.zeros(cap, np.int32)
+        torch.cuda.synchronize(self.device)
+        n = self.lib.tsc_snapshot(self.h, rep, cap, drv.ctypes.data, dist.ctypes.data,
+                                  speed.ctypes.data, vid.ctypes.data)
+        if n < 0:
+            _lib.check(n, "tsc_snapshot")
+        return drv[:n], dist[:n], speed[:n], vid[:n]
+
+    def errors(self):
+        e = C.c_int32(0)
+        _lib.check(self.lib.tsc_errors(self.h, C.byref(e)), "tsc_errors")
+        return e.value
+
+    def mean_vehicles(self):
+        m = C.c_double(0)
+        _lib.check(self.lib.tsc_mean_vehicles(self.h, C.byref(m)), "tsc_mean_vehicles")
+        return m.value

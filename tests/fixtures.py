@@ -1,0 +1,38 @@
+"""Loading of the golden fixtures (tests/golden/<case>/)."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+from pytsc_amd.config import Config
+from pytsc_amd.flows import expand_flows
+from pytsc_amd.grid import generate_grid
+from pytsc_amd.scenario import build_tables
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(
+    d for d in os.listdir(GOLDEN) if os.path.exists(os.path.join(GOLDEN, d, "expected.npz"))
+)
+
+
+def load_case(name, n_replicas=1):
+    d = os.path.join(GOLDEN, name)
+    with gzip.open(os.path.join(d, "inputs.json.gz"), "rt") as f:
+        inputs = json.load(f)
+    exp = dict(np.load(os.path.join(d, "expected.npz")))
+    with open(os.path.join(d, "parser.json")) as f:
+        parser = json.load(f)
+    if "grid" in inputs["roadnet"]:
+        net = generate_grid(*inputs["roadnet"]["grid"])
+    else:
+        net = inputs["roadnet"]["net"]
+    entries = expand_flows(inputs["flows"])
+    cfg = Config(
+        name,
+        hip={"roadnet_json": net, "flow_entries": [entries]},
+        signal=dict(inputs["signal"]),
+        misc=dict(inputs["misc"]),
+    )
+    tables = build_tables(cfg, n_replicas=n_replicas)
+    return inputs, exp, parser, cfg, tables
