@@ -39,6 +39,10 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m pytsc_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback."
         )
+    # torch first: the library must bind to the SAME HIP runtime (libamdhip64) that
+    # torch has loaded, since it operates on torch-owned device buffers and streams.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.tsc_abi_version.restype = C.c_int

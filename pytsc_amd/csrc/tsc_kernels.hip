@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
       nd -= L;
       fl = TSC_F_MOVED;
       if (!is_link && aux < 0) fl = TSC_F_MOVED | TSC_F_ENDED;
+      else if (!is_link && nd > N.drv_length[aux]) atomicAdd(&S.errors[3], 1); // double hand-off: unsupported
       if (n_out < TSC_OB_MAX) {
         ob |= (i & 1023) << (2 + 10 * n_out);
         size_t ox = ((size_t)d * TSC_OB_MAX + n_out) * (size_t)S.RS + (size_t)r;
