@@ -1,0 +1,196 @@
+"""Benchmark of the step() hot path: agent-env-steps/s on the 4x4 grid.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one env step of every replica: apply actions -> 5 engine sub-steps ->
+measure -> observations / rewards / masks (tsc_step through the C-ABI), driven by
+an on-device random-valid-action policy.  Inputs are synthetic (Poisson demand,
+SURVEY.md §8(d) config 2) and resident in HBM before the timed region.  Replicas
+shard across ranks with no collective on the step path (weak scaling: 4096
+replicas per GPU); torch.distributed is used only for the barrier around the
+timed region and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline object of the
+dominant kernel (k_action, timed live with HIP events on its stream) and the CPU
+baseline (the scalar oracle on one host core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets):
+    from pytsc_amd.config import Config
+    from pytsc_amd.scenario import build_tables
+
+    cfg = Config(
+        f"syn_{rows}x{cols}",
+        signal={"action_space": "phase_selection", "round_robin": False},
+        hip={"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0},
+    )
+    return build_tables(cfg, n_replicas=n_replicas, set_offset=set_offset)
+
+
+def cpu_baseline(rows, cols, rate, warmup, budget_s):
+    """The scalar f64 CPU oracle ("port": a restatement, not CityFlow) on ONE host
+    core, same network + demand (flow set 0), same random-valid policy; bounded
+    sample.  Test-infrastructure code used here only as the measured baseline."""
+    import numpy as np
+
+    from oracle.pyoracle import Oracle
+
+    tables = workload_tables(rows, cols, 1, 0, rate, 1)
+    orc = Oracle(tables)
+    rng = np.random.default_rng(0)
+    out = orc.observe()
+    A = tables.n_agents
+
+    def act(mask):
+        u = rng.random(mask.shape) * mask
+        return u.argmax(-1).astype(np.int32)
+
+    for _ in range(warmup):
+        out = orc.step(act(out.mask[0])[None])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        out = orc.step(act(out.mask[0])[None])
+        n += 1
+        if out.terminated[0]:  # simulated hour over: restart, as pytsc restart() does
+            orc.reset()
+            out = orc.observe()
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {
+        "value": A * n / dt, "unit": "agent-env-steps/s", "cores": 1, "kind": "port",
+        "sample": f"CPU restatement (oracle), not CityFlow: 1 replica of the same {rows}x{cols} "
+                  f"workload, {n} env steps after {warmup} warm-up steps, {dt:.1f} s on 1 of "
+                  f"{os.cpu_count()} host cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
+    ap.add_argument("--rows", type=int, default=4)
+    ap.add_argument("--cols", type=int, default=4)
+    ap.add_argument("--rate", type=float, default=700.0, help="veh/h per entry road")
+    ap.add_argument("--flow-sets", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--outputs", default="obs,mask,local_reward,global_reward,done,terminated")
+    args = ap.parse_args()
+
+    import torch
+
+    from pytsc_amd import sharding
+    from pytsc_amd.vec_env import VecEngine
+
+    rank, local_rank, world_size = sharding.init()
+    if world_size != args.gpus and world_size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    R = args.replicas
+    tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, args.flow_sets)
+    A = tables.n_agents
+    eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")))
+    torch.manual_seed(0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    buf = eng.observe()
+    nact = eng.n_actions
+    u = torch.empty((R, A, nact), device=dev, dtype=torch.float32)
+
+    def policy(mask):
+        # uniform among mask-valid actions, on device: argmax of U(0,1) * mask
+        u.uniform_(1e-6, 1.0, generator=gen)
+        return (u * mask).argmax(-1).to(torch.int32)
+
+    def reset_finished(buf):
+        # restart() of replicas whose simulated hour is over (pytsc/__init__.py:164-176)
+        eng.reset(buf["terminated"])
+
+    check_every = 720 // 4
+    for i in range(args.warmup):
+        buf = eng.step(policy(buf["mask"]))
+        if (i + 1) % check_every == 0:
+            reset_finished(buf)
+    torch.cuda.synchronize(dev)
+    v0 = eng.mean_vehicles()
+    eng.profile(True)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        buf = eng.step(policy(buf["mask"]))
+        if (i + 1) % check_every == 0:
+            reset_finished(buf)
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, device=dev if world_size > 1 else "cpu")
+    k_ms, k_n = eng.profile_read()
+    eng.profile(False)
+    v1 = eng.mean_vehicles()
+    errors = eng.errors()
+    total_units = sharding.sum_over_ranks(R * A * args.steps, device=dev if world_size > 1 else "cpu")
+    value = total_units / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        # roofline of the dominant kernel: algorithmic bytes per
+        # agent-env-step B = 48*V_a + 1356; one k_action launch
+        # advances R*A agents by one of the delta_time sub-steps = R*A/5 units.
+        va = 0.5 * (v0 + v1) / A
+        bytes_per_unit = 48.0 * va + 1356.0
+        units_per_launch = R * A / 5.0
+        avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
+        achieved = bytes_per_unit * units_per_launch / avg_launch_s / 1e9 if k_n else None
+        line = {
+            "metric": "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X",
+            "value": value, "unit": "agent-env-steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson "
+                            f"{args.rate:g} veh/h per entry road, {R} env replicas per GPU, "
+                            f"phase_selection action space, random valid actions, "
+                            f"outputs {args.outputs}",
+                "replicas_per_gpu": R, "agents": A, "sub_steps_per_env_step": 5,
+                "mean_live_vehicles_per_replica": 0.5 * (v0 + v1), "device_errors": errors,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "kernel": "k_action", "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
+                "bytes_per_agent_env_step": bytes_per_unit, "V_a": va,
+                "note": "latency/occupancy-bound f64 scalar work, not HBM-bound (DESIGN.md §5)",
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.rows, args.cols, args.rate, min(args.warmup, 120),
+                                                args.cpu_budget)
+        print(json.dumps(line))
+    eng.close()
+    if world_size > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libpytsc_amd.so")
 SYMBOLS = (
     "tsc_abi_version", "tsc_create", "tsc_destroy", "tsc_reset", "tsc_step", "tsc_observe",
     "tsc_lane_detail", "tsc_snapshot", "tsc_errors", "tsc_mean_vehicles", "tsc_obs_size",
-    "tsc_state_size", "tsc_n_actions",
+    "tsc_state_size", "tsc_n_actions", "tsc_profile_enable", "tsc_profile_read",
 )
 
 ERRORS = {-1: "TSC_EINVAL (bad argument / inconsistent tables)",
@@ -56,6 +56,8 @@ def load():
     lib.tsc_snapshot.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.tsc_errors.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.tsc_mean_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.tsc_profile_enable.argtypes = [vp, C.c_int]
+    lib.tsc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     for f in ("tsc_obs_size", "tsc_state_size", "tsc_n_actions"):
         getattr(lib, f).argtypes = [vp]
     if lib.tsc_abi_version() != 1:

@@ -127,3 +127,11 @@ class VecEngine:
         m = C.c_double(0)
         _lib.check(self.lib.tsc_mean_vehicles(self.h, C.byref(m)), "tsc_mean_vehicles")
         return m.value
+
+    def profile(self, on):
+        _lib.check(self.lib.tsc_profile_enable(self.h, 1 if on else 0), "tsc_profile_enable")
+
+    def profile_read(self):
+        ms, n = C.c_double(0), C.c_int32(0)
+        _lib.check(self.lib.tsc_profile_read(self.h, C.byref(ms), C.byref(n)), "tsc_profile_read")
+        return ms.value, n.value
