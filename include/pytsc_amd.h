@@ -241,7 +241,9 @@ int tsc_destroy(tsc_handle_t h);
 int tsc_reset(tsc_handle_t h, const uint8_t *reset_mask_dev, void *stream);
 
 /* One env step for all replicas: apply actions_dev[R, A], advance delta_time
- * engine sub-steps, measure, and fill the requested outputs. */
+ * engine sub-steps, measure, and fill the requested outputs.  An action of -1
+ * leaves that signal untouched (phase and time_on_phase), as when the reference
+ * does not call switch_phase for it; actions_dev == NULL leaves all untouched. */
 int tsc_step(tsc_handle_t h, const int32_t *actions_dev,
              const tsc_step_out_t *out, void *stream);
 

@@ -1085,7 +1085,8 @@ int tsco_step(void *h, const int32_t *actions, const tsc_step_out_t *out) {
   for (int i = 0; i < o->cfg.n_replicas; i++) {
     rep_t *r = &o->rep[i];
     for (int a = 0; a < n->n_agents; a++) {
-      int act = actions[(size_t)i * n->n_agents + a];
+      int act = actions ? actions[(size_t)i * n->n_agents + a] : -1;
+      if (act == -1) continue; /* signal left untouched */
       int np_ = n->agent_n_phases[a];
       int target;
       if (o->cfg.action_space == TSC_ACT_PHASE_SWITCH) target = act == 1 ? (r->cur_idx[a] + 1) % np_ : r->cur_idx[a];

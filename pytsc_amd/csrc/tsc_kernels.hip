@@ -715,6 +715,7 @@ __global__ __launch_bounds__(256) void k_phase(DevNet N, DevState S, DevCfg C, c
   int r = rb * 64 + threadIdx.x;
   if (a >= N.n_agents || r >= S.R) return;
   int act = actions[(size_t)r * N.n_agents + a];
+  if (act == -1) return; // signal left untouched (no switch_phase call in the reference)
   int np_ = N.agent_n_phases[a];
   int cur = S.cur_idx[IDX(a)];
   int target;

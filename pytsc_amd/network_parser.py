@@ -11,13 +11,13 @@ surface consumes: ``traffic_signals`` (roadnet-file order,
 """
 import numpy as np
 
-from pytsc_amd.roadnet import RoadNet
+from pytsc_amd.roadnet import load_roadnet
 
 
 class NetworkParser:
     def __init__(self, config, roadnet=None):
         self.config = config
-        self.rn = roadnet if roadnet is not None else RoadNet.from_file(config.roadnet_file)
+        self.rn = roadnet if roadnet is not None else load_roadnet(config)
         self.net = self.rn.net
         self._build()
 

@@ -260,3 +260,15 @@ class RoadNet:
     def road_lanes(self, road_id):
         n = len(self.road_by_id[road_id]["lanes"])
         return [self.lane_index[f"{road_id}_{i}"] for i in range(n)]
+
+
+def load_roadnet(config):
+    """RoadNet of a Config: in-memory dict, synthetic syn_RxC grid, or file."""
+    if "roadnet_json" in config.simulator:
+        return RoadNet(config.simulator["roadnet_json"])
+    if config.synthetic_grid is not None:
+        from pytsc_amd.grid import generate_grid
+
+        rows, cols = config.synthetic_grid
+        return RoadNet(generate_grid(rows, cols))
+    return RoadNet.from_file(config.roadnet_file)

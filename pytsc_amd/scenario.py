@@ -2,19 +2,9 @@
 import os
 
 from pytsc_amd.flows import FlowCompiler, load_flow_file, poisson_flows
-from pytsc_amd.grid import generate_grid
 from pytsc_amd.network_parser import NetworkParser
-from pytsc_amd.roadnet import RoadNet
+from pytsc_amd.roadnet import load_roadnet
 from pytsc_amd.tables import Tables
-
-
-def load_roadnet(config):
-    if "roadnet_json" in config.simulator:
-        return RoadNet(config.simulator["roadnet_json"])
-    if config.synthetic_grid is not None:
-        rows, cols = config.synthetic_grid
-        return RoadNet(generate_grid(rows, cols))
-    return RoadNet.from_file(config.roadnet_file)
 
 
 def flow_entry_sets(config, rn):

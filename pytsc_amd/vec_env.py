@@ -135,3 +135,82 @@ class VecEngine:
         ms, n = C.c_double(0), C.c_int32(0)
         _lib.check(self.lib.tsc_profile_read(self.h, C.byref(ms), C.byref(n)), "tsc_profile_read")
         return ms.value, n.value
+
+
+class VecTrafficSignalNetwork:
+    """Batched façade: the reference's TrafficSignalNetwork API
+    (pytsc/__init__.py:17-182) with a leading replica axis and torch tensors in
+    HBM instead of Python lists.  Uses the scenario's configured action space
+    and its device-side masks."""
+
+    def __init__(self, scenario, simulator_backend="hip", n_replicas=1024, device=0, set_offset=0,
+                 outputs=("obs", "state", "mask", "local_reward", "global_reward", "done", "terminated",
+                          "stats"), **kwargs):
+        from pytsc_amd.config import Config
+        from pytsc_amd.scenario import build_tables
+
+        self.config = Config(scenario, **kwargs)
+        self.tables = build_tables(self.config, n_replicas=n_replicas, set_offset=set_offset)
+        self.parsed_network = self.tables.parser
+        self.engine = VecEngine(self.tables, device=device, want=tuple(outputs))
+        self.n_replicas = n_replicas
+        self.n_agents = self.tables.n_agents
+        self.agent_ids = list(self.parsed_network.traffic_signals.keys())
+        self.buf = self.engine.observe()
+        self.episode_count = 0
+
+    @property
+    def episode_limit(self):
+        return int(self.config.simulator["episode_limit"] / self.config.simulator["delta_time"])
+
+    def get_observation_size(self):
+        return self.engine.obs_size
+
+    def get_state_size(self):
+        return self.engine.state_size
+
+    def get_action_size(self):
+        return self.engine.n_actions
+
+    def get_observations(self):
+        return self.buf["obs"]
+
+    def get_state(self):
+        return self.buf["state"]
+
+    def get_action_mask(self):
+        return self.buf["mask"]
+
+    def get_reward(self):
+        return self.buf["global_reward"]
+
+    def get_rewards(self):
+        return self.buf["local_reward"]
+
+    def get_env_info(self):
+        """dict of [R] tensors, keys as the reference's get_step_stats (metrics.py:221-237)."""
+        st = self.buf["stats"]
+        info = {k: st[:, i] for i, k in enumerate(STAT_KEYS)}
+        info["episode_limit"] = self.episode_limit
+        return info
+
+    def step(self, actions):
+        """actions [R, A] int32 -> (global_reward [R], episode_over [R], info)."""
+        self.buf = self.engine.step(actions)
+        return self.buf["global_reward"], self.buf["done"], self.get_env_info()
+
+    def restart(self):
+        """Restart the replicas whose simulated hour is over (pytsc/__init__.py:164-176)."""
+        self.engine.reset(self.buf["terminated"])
+
+    def reset_all(self):
+        self.engine.reset()
+        self.buf = self.engine.observe()
+
+    def random_valid_actions(self, generator=None):
+        m = self.buf["mask"]
+        u = torch.rand(m.shape, device=m.device, generator=generator).clamp_min_(1e-6)
+        return (u * m).argmax(-1).to(torch.int32)
+
+    def close(self):
+        self.engine.close()
