@@ -6,7 +6,7 @@
  *     reference's Python (file:line cited at each function), and is pinned by
  *     the golden fixtures under tests/golden/ that were produced by importing
  *     the reference's own Python layer on top of this engine
- *     (tools/gen_golden.py);
+ *     (tests/golden/gen_golden.py);
  *   - the engine sub-step restates the published algorithm of the third-party
  *     dependency CityFlow (cityflow-project/CityFlow; PyTSC pins no version,
  *     it is absent from /root/reference and cannot be built here), anchored on
