@@ -19,6 +19,16 @@
 #define TSC_F_ENDED 2
 #define TSC_OB_MAX 3
 
+// One cross of a lane-link, 32 bytes so the wave-uniform scan fetches it with one scalar load.
+struct CrossRec {
+  double x;   // distance of the cross on this link
+  double xo;  // distance of the cross on the other link
+  int other;  // the other lane-link (drivable index)
+  int meta;   // local index of the other link (bits 0-7) | its road-link type << 8
+  int pe;     // entry of the same cross in the other link's list
+  int pad;
+};
+
 struct DevNet {
   int n_lanes, n_links, n_drv, n_agents, n_routes, n_tmpl, single_tmpl;
   int max_links_per_agent;
@@ -30,8 +40,10 @@ struct DevNet {
   const int *link_start_lane, *link_end_lane, *link_type, *link_agent, *link_local;
   const uint32_t *link_avail_mask;
   const unsigned long long *link_conflict; // local-index mask of links crossing this link
-  const int *link_cross_ptr, *cross_other;
+  const unsigned long long *agent_phase_avail; // [n_agents*32]: local-index mask of links available in raw phase p
+  const int *link_cross_ptr, *cross_other, *cross_peer; // cross_peer: entry of the same cross in the other link's list
   const double *cross_dist_self, *cross_dist_other;
+  const CrossRec *cross_rec; // [n_cross + 4], padded for the software-pipelined scan
   const int *agent_link_ptr, *agent_links; // CSR: links of an agent in local order
   const int *agent_n_phases, *agent_phase_raw, *agent_phase_green, *agent_phase_min, *agent_phase_max;
   const int *agent_inc_ptr, *agent_inc_lanes, *agent_out_ptr, *agent_out_lanes;
@@ -47,13 +59,15 @@ struct DevNet {
 
 struct DevState {
   int R, RS; // replicas, row stride (R rounded up to 64)
+  int n_slots; // total vehicle slots per replica (rows of the tiled slot arrays)
   // per slot [S_total * RS]
-  double *dist, *speed, *ndist, *nspeed;
-  int *tag, *aux, *blk, *nblk;
-  unsigned char *nflag;
+  double *dist, *speed;   // committed half (read by k_notify / k_action / k_measure)
+  double *ndist, *nspeed; // the other half: written by k_action, patched by k_commit, then swapped in
+  int *tag, *aux, *blk;   // blk: blocker word (TSC_BLK_*), updated in place
   // per drivable [n_drv * RS]
   int *cnt, *ob, *tail_tag, *tail_prev;
   int *obx_tag, *obx_aux, *obx_blk; // [n_drv * TSC_OB_MAX * RS] records of this sub-step's leavers
+  double *obx_dist, *obx_speed;
   double *tail_dist, *tail_speed;
   // per lane [n_lanes * RS]
   int *spawn_cur, *lane_n, *lane_q;
@@ -66,13 +80,14 @@ struct DevState {
   // per replica [RS]
   int *t, *set, *restarts, *fin_cnt;
   unsigned long long *fin_dsum, *fin_ssum; // sums over finished vehicles: duration, creation step
-  // per vid [max_veh * RS]
-  int *blocker_by_vid;
+  // per vid [max_veh * RS]: committed blocker of a running vehicle, ping-pong halves
+  int *bbv, *nbbv;
   int *errors; // [4]: slot overflow, outbox overflow, bad action, other
 };
 
 struct DevCfg {
   int delta_time, yellow_time, action_space, round_robin, visibility, sim_length, episode_limit;
   int initial_wait_time, set_offset, sequential_sets, reward_kind, n_actions, obs_size, state_size;
+  int ablate; // diagnostic builds only (TSC_ABLATE env): skip parts of k_action to price them; 0 in every real run
   double interval, veh_size_min_gap, flickering_coef;
 };

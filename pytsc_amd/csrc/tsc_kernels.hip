@@ -20,6 +20,10 @@
 #include "tsc_device.h"
 
 #define IDX(row) ((size_t)(row) * (size_t)S.RS + (size_t)r)
+// Vehicle-slot arrays are tiled by 64-replica block: [replica block][slot row][64 lanes].
+// One wavefront's slots of one lane are then a few KB of contiguous memory per field
+// (consecutive rows 512 B apart instead of RS*8 bytes): DRAM-page and TLB friendly.
+#define SIDX(row) ((((size_t)r >> 6) * (size_t)S.n_slots + (size_t)(row)) * 64 + ((size_t)r & 63))
 
 struct Tm {
   double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
@@ -148,39 +152,41 @@ __global__ __launch_bounds__(256) void k_notify(DevNet N, DevState S, int n_rb, 
     if ((he & TSC_CNT_MASK) > 0 && !(he & TSC_NEW_BIT) && S.tail_prev[IDX(e)] == link) oe |= bit;
     int sl = N.link_start_lane[k];
     int hs = S.cnt[IDX(sl)];
-    if ((hs & TSC_CNT_MASK) > 0 && S.aux[IDX(N.drv_slot_base[sl])] == link) os |= bit;
+    if ((hs & TSC_CNT_MASK) > 0 && S.aux[SIDX(N.drv_slot_base[sl])] == link) os |= bit;
   }
   S.occ_e[IDX(a)] = oe;
   S.occ_v[IDX(a)] = ov;
   S.occ_s[IDX(a)] = os;
 }
 
-// ---------------------------------------------------------------- k_action
+// ------------------------------------------------------------------ find_foe
 struct Foe {
-  bool found;
   double d2, speed;
   int vid, ell, tmpl;
 };
 
-// The vehicle that the engine's notifyCross would have registered for the cross
-// at distance `xo` on lane-link `other`: first of (E, link vehicles front to
-// back, S) whose rear has not yet cleared the cross.
+// The vehicle the engine's notifyCross registers for the
+// cross at distance `xo` on lane-link `other` (wave-uniform): the first of
+//   E  the tail of the end lane, if it came from this link,
+//   V  the vehicles on the link, front to back,
+//   S  the head of the start lane, if it is heading here on green,
+// whose rear has not yet cleared the cross.  Resolved lazily, only for links
+// whose bit is set in the per-intersection occupancy masks.
 template <bool SINGLE>
-__device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int r, int vbase, int other, double xo,
-                                        unsigned long long oe, unsigned long long ov, unsigned long long os,
-                                        int raw_phase) {
+__device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int r, int vbase, int other, int bitpos,
+                                        double xo, unsigned long long oe, unsigned long long ov,
+                                        unsigned long long os_green) {
   Foe f;
-  f.found = false;
   f.d2 = 0;
   f.speed = 0;
   f.vid = -1;
   f.ell = 0x7fffffff;
   f.tmpl = 0;
-  int k = other - N.n_lanes;
-  unsigned long long bit = 1ull << N.link_local[k];
-  double Lo = N.drv_length[other];
+  const int k = other - N.n_lanes;
+  const unsigned long long bit = 1ull << bitpos;
+  const double Lo = N.drv_length[other];
   if (oe & bit) {
-    int e = N.link_end_lane[k];
+    const int e = N.link_end_lane[k];
     double td = S.tail_dist[IDX(e)];
     int ttag = S.tail_tag[IDX(e)];
     int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
@@ -188,57 +194,48 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
     double crossDistance = Lo - xo;
     double vehDistance = td - tlen;
     if (crossDistance + vehDistance < 0) {
-      f.found = true;
       f.d2 = -(td + crossDistance);
       f.speed = S.tail_speed[IDX(e)];
       f.vid = TSC_TAG_VID(ttag);
       f.tmpl = tt;
-      return f;
     }
   }
-  if (ov & bit) {
+  if (f.vid < 0 && (ov & bit)) {
     int n = S.cnt[IDX(other)] & TSC_CNT_MASK;
-    int sb = N.drv_slot_base[other];
+    const int sb = N.drv_slot_base[other];
     for (int j = 0; j < n; j++) {
-      double dj = S.dist[IDX(sb + j)];
-      int tg = S.tag[IDX(sb + j)];
+      double dj = S.dist[SIDX(sb + j)];
+      int tg = S.tag[SIDX(sb + j)];
       int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tg));
       double tlen = N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
-      bool claim;
-      if (dj > xo) claim = (dj - xo - tlen <= 0);
-      else claim = true;
-      if (claim) {
-        f.found = true;
-        f.d2 = xo - dj;
-        f.speed = S.speed[IDX(sb + j)];
-        f.vid = TSC_TAG_VID(tg);
-        f.ell = S.aux[IDX(sb + j)];
-        f.tmpl = tt;
-        return f;
-      }
+      if (dj > xo && !(dj - xo - tlen <= 0)) continue; // rear already past the cross: next vehicle
+      f.d2 = xo - dj;
+      f.speed = S.speed[SIDX(sb + j)];
+      f.vid = TSC_TAG_VID(tg);
+      f.ell = S.aux[SIDX(sb + j)];
+      f.tmpl = tt;
+      break;
     }
   }
-  if ((os & bit) && ((N.link_avail_mask[k] >> raw_phase) & 1u)) {
-    int sl = N.link_start_lane[k];
-    int s0 = N.drv_slot_base[sl];
-    double ds = S.dist[IDX(s0)];
-    int tg = S.tag[IDX(s0)];
-    f.found = true;
+  if (f.vid < 0 && (os_green & bit)) {
+    const int sl = N.link_start_lane[k];
+    const int s0 = N.drv_slot_base[sl];
+    double ds = S.dist[SIDX(s0)];
+    int tg = S.tag[SIDX(s0)];
     f.d2 = (N.drv_length[sl] - ds) + xo;
-    f.speed = S.speed[IDX(s0)];
+    f.speed = S.speed[SIDX(s0)];
     f.vid = TSC_TAG_VID(tg);
     f.tmpl = tmpl_of<SINGLE>(N, vbase, f.vid);
   }
   return f;
 }
 
+// ---------------------------------------------------------------- k_action
 // Cross::canPass
 __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &S, int r, double speed, const Tm &t,
-                                               int vid, int ell, int link, int other, double d1, const Foe &f,
+                                               int vid, int ell, int t1, int t2, double d1, const Foe &f,
                                                double interval) {
   Tm tf = load_tm(N, f.tmpl);
-  int t1 = N.link_type[link - N.n_lanes];
-  int t2 = N.link_type[other - N.n_lanes];
   double d2 = f.d2;
   if (!can_yield(speed, t, d1)) return true;
   int yield = 0;
@@ -278,15 +275,15 @@ __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &
       }
     }
   }
-  if (yield == 1) {
+  if (yield == 1 && !(S.R < 0)) {
     // blocker-chain cycle check (Floyd) over the committed blockers
     int fast = f.vid, slow = f.vid;
     for (int guard = 0; guard < 4096; guard++) {
       if (fast < 0) break;
-      int bf = S.blocker_by_vid[IDX(fast)];
+      int bf = S.bbv[IDX(fast)];
       if (bf < 0) break;
-      slow = S.blocker_by_vid[IDX(slow)];
-      fast = S.blocker_by_vid[IDX(bf)];
+      slow = S.bbv[IDX(slow)];
+      fast = S.bbv[IDX(bf)];
       if (slow == fast) {
         yield = -1;
         break;
@@ -296,13 +293,60 @@ __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &
   return yield == -1;
 }
 
+// Blocker word of a slot: low 24 bits = blocker vid + 1 (0 = none); bit 30 = the
+// vehicle had a blocker one step earlier (so the entry of the other ping-pong
+// half of blocker_by_vid is refreshed once more after a blocker disappears).
+#define TSC_BLK_VID(w) ((int)((w) & 0xffffff) - 1)
+#define TSC_BLK_OLDER(w) (((w) >> 30) & 1)
+#define TSC_HSCAN 12 /* slots of a lane scanned by k_action for vehicles near the lane end */
+
+// Resolve the cross conflicts of one vehicle on / approaching lane-link `link`
+// (wave-uniform): first cross ahead, in distance order, that it may not pass.
 template <bool SINGLE>
+__device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, int r, int vbase, int link, bool mine,
+                                           double speed, const Tm &t, int vid, int ell, double dts,
+                                           unsigned long long oe, unsigned long long ov, unsigned long long os_green,
+                                           double interval, double &s, int &nblk, int ablate = 0) {
+  const int k = link - N.n_lanes;
+  unsigned long long active = mine ? (N.link_conflict[k] & (oe | ov | os_green)) : 0ull;
+  if (!__builtin_amdgcn_ballot_w64(active != 0)) return; // wave-uniform early out
+  const int t1 = N.link_type[k];
+  bool stop = active == 0;
+  const int cb = N.link_cross_ptr[k], ce = N.link_cross_ptr[k + 1];
+  CrossRec cur = N.cross_rec[cb]; // wave-uniform: one 32-byte scalar load per cross, fetched one ahead
+  for (int e = cb; e < ce; e++) {
+    const CrossRec nxt = N.cross_rec[e + 1];
+    const bool want = !stop && cur.x >= dts && ((active >> (cur.meta & 255)) & 1ull);
+    if (__builtin_amdgcn_ballot_w64(want) && !(ablate & 128)) {
+      if (want) {
+        Foe f = find_foe<SINGLE>(N, S, r, vbase, cur.other, cur.meta & 255, cur.xo, oe, ov, os_green);
+        if (f.vid >= 0 && !(ablate & 64)) {
+          double d1 = cur.x - dts;
+          if (!cross_can_pass(N, S, r, speed, t, vid, ell, t1, cur.meta >> 8, d1, f, interval)) {
+            s = min2(s, stop_before_speed(speed, t, cur.x - dts - t.yieldDist, interval));
+            nblk = f.vid;
+            stop = true;
+          }
+        }
+      }
+    }
+    cur = nxt;
+  }
+}
+
+// One wavefront = 64 replicas of ONE drivable: every static-table access below is
+// wave-uniform (scalar), every state access is coalesced along the replica axis.
+// For lanes the per-vehicle choice of the next lane-link (`aux`) differs between
+// replicas, so the code iterates over the lane's (<= 3) outgoing links with a
+// wave-uniform loop and lets each replica act in the iteration of its own link.
+template <bool SINGLE, bool IS_LINK>
 __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, int n_rb, int n_dblk) {
   int rb, dblk;
   if (!map_block(n_rb, n_dblk, rb, dblk)) return;
-  int d = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
+  int row = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
   int r = rb * 64 + threadIdx.x;
-  if (d >= N.n_drv || r >= S.R) return;
+  if (row >= (IS_LINK ? N.n_links : N.n_lanes) || r >= S.R) return;
+  const int d = IS_LINK ? N.n_lanes + row : row;
   int hdr = S.cnt[IDX(d)];
   int n = hdr & TSC_CNT_MASK;
   if (n == 0) {
@@ -310,26 +354,61 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
     return;
   }
   const double interval = C.interval;
-  const bool is_link = d >= N.n_lanes;
   const double L = N.drv_length[d];
   const double drvMax = N.drv_max_speed[d];
   const int sb = N.drv_slot_base[d];
   const int vbase = SINGLE ? 0 : N.set_veh_ptr[S.set[r]];
-  const int kd = is_link ? d - N.n_lanes : 0;
-  const int my_agent = is_link ? N.link_agent[kd] : -1;
-  const int end_lane = is_link ? N.link_end_lane[kd] : -1;
+  const int end_lane = IS_LINK ? N.link_end_lane[row] : -1;
+  const int qb = IS_LINK ? 0 : N.lane_out_ptr[d], qe = IS_LINK ? 0 : N.lane_out_ptr[d + 1];
+  // the signal that owns this lane's end / this link (wave-uniform); -1: lane ends at a virtual node
+  const int ag = IS_LINK ? N.link_agent[row] : (qb < qe ? N.link_agent[N.lane_out_links[qb] - N.n_lanes] : -1);
+  const double *__restrict__ g_dist = S.dist;
+  const double *__restrict__ g_speed = S.speed;
+  const int *__restrict__ g_tag = S.tag;
+  const int *__restrict__ g_aux = S.aux;
+  double *__restrict__ o_dist = S.ndist;
+  double *__restrict__ o_speed = S.nspeed;
+
+  int raw = 0;
+  unsigned long long oe = 0, ov = 0, os_green = 0; // cross candidates of this intersection (k_notify)
+  if (ag >= 0) {
+    raw = S.raw_phase[IDX(ag)];
+    oe = S.occ_e[IDX(ag)];
+    ov = S.occ_v[IDX(ag)];
+    // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
+    os_green = S.occ_s[IDX(ag)] & N.agent_phase_avail[(size_t)ag * 32 + raw];
+  }
 
   double p_dist = 0, p_speed = 0;
   int p_tmpl = 0;
   int ob = 0, n_out = 0;
-  for (int i = 0; i < n; i++) {
-    double dist = S.dist[IDX(sb + i)];
-    double speed = S.speed[IDX(sb + i)];
-    int tag = S.tag[IDX(sb + i)];
-    int aux = S.aux[IDX(sb + i)];
+  // software pipeline: the next slot's loads are issued before this slot's stores
+  double c_dist = g_dist[SIDX(sb)], c_speed = g_speed[SIDX(sb)];
+  int c_tag = g_tag[SIDX(sb)], c_aux = g_aux[SIDX(sb)], c_blk = S.blk[SIDX(sb)];
+  // Lanes: this kernel handles the head vehicle and the vehicles within the
+  // approach distance of the lane end (they form a prefix of the list, scanned up
+  // to TSC_HSCAN slots); every other vehicle is a plain follower and is advanced
+  // by k_follow with the same predicate.
+  const int n_scan = IS_LINK ? n : (n < TSC_HSCAN ? n : TSC_HSCAN);
+  for (int i = 0; i < n_scan; i++) {
+    const double dist = c_dist, speed = c_speed;
+    const int tag = c_tag, aux = c_aux, blkw = c_blk;
+    if (i + 1 < n_scan) {
+      c_dist = g_dist[SIDX(sb + i + 1)];
+      c_speed = g_speed[SIDX(sb + i + 1)];
+      c_tag = g_tag[SIDX(sb + i + 1)];
+      c_aux = g_aux[SIDX(sb + i + 1)];
+      c_blk = S.blk[SIDX(sb + i + 1)];
+    }
     int vid = TSC_TAG_VID(tag);
     int tid = tmpl_of<SINGLE>(N, vbase, vid);
     Tm t = load_tm(N, tid);
+    if (!IS_LINK && i > 0 && !((L - dist) <= t.approach)) { // a follower: k_follow's
+      p_dist = dist;
+      p_speed = speed;
+      p_tmpl = tid;
+      continue;
+    }
 
     // ---- leader and gap (engine: updateLeaderAndGap)
     bool has_leader = false;
@@ -341,16 +420,26 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
       gap = p_dist - plen - dist;
       vL = p_speed;
       l_tmpl = p_tmpl;
-    } else {
+    } else if (!(C.ablate & 2)) {
       double dis = L - dist;
       double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * interval * 2;
-      int lane_to_check = -1;
-      if (is_link) {
-        lane_to_check = end_lane;
+      if (IS_LINK) {
+        int he = S.cnt[IDX(end_lane)];
+        int ne = (he & TSC_CNT_MASK) - ((he & TSC_NEW_BIT) ? 1 : 0); // tail before this step's insertion
+        if (ne > 0) {
+          int ttag = S.tail_tag[IDX(end_lane)];
+          int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+          has_leader = true;
+          gap = dis + S.tail_dist[IDX(end_lane)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+          vL = S.tail_speed[IDX(end_lane)];
+          l_tmpl = tt;
+        }
       } else if (aux >= 0) {
         // all lane-links leaving this lane may overlap: nearest tail wins
-        for (int q = N.lane_out_ptr[d]; q < N.lane_out_ptr[d + 1]; q++) {
-          int ll = N.lane_out_links[q];
+        double my_len = 0;
+        for (int q = qb; q < qe; q++) {
+          const int ll = N.lane_out_links[q];
+          if (ll == aux) my_len = N.drv_length[ll];
           int nl = S.cnt[IDX(ll)] & TSC_CNT_MASK;
           if (nl > 0) {
             int ttag = S.tail_tag[IDX(ll)];
@@ -365,22 +454,26 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
           }
         }
         if (!has_leader) {
-          dis += N.drv_length[aux];
-          if (!(dis > limit)) lane_to_check = N.link_end_lane[aux - N.n_lanes];
+          dis += my_len;
+          if (!(dis > limit)) {
+            for (int q = qb; q < qe; q++) {
+              const int ll = N.lane_out_links[q];
+              const int el = N.link_end_lane[ll - N.n_lanes];
+              if (ll != aux) continue;
+              int he = S.cnt[IDX(el)];
+              int ne = (he & TSC_CNT_MASK) - ((he & TSC_NEW_BIT) ? 1 : 0);
+              if (ne > 0) {
+                int ttag = S.tail_tag[IDX(el)];
+                int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+                has_leader = true;
+                gap = dis + S.tail_dist[IDX(el)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+                vL = S.tail_speed[IDX(el)];
+                l_tmpl = tt;
+              }
+              // beyond: a whole lane further is past the look-ahead limit (checked at create)
+            }
+          }
         }
-      }
-      if (lane_to_check >= 0) {
-        int he = S.cnt[IDX(lane_to_check)];
-        int ne = (he & TSC_CNT_MASK) - ((he & TSC_NEW_BIT) ? 1 : 0); // tail before this step's insertion
-        if (ne > 0) {
-          int ttag = S.tail_tag[IDX(lane_to_check)];
-          int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
-          has_leader = true;
-          gap = dis + S.tail_dist[IDX(lane_to_check)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
-          vL = S.tail_speed[IDX(lane_to_check)];
-          l_tmpl = tt;
-        }
-        // beyond: a whole lane further is past the look-ahead limit (checked at create)
       }
     }
 
@@ -388,67 +481,56 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
     double v = t.maxSpeed;
     v = min2(v, speed + t.maxPosAcc * interval);
     v = min2(v, drvMax);
-    if (has_leader) {
+    if (has_leader && !(C.ablate & 4)) {
       Tm tl = load_tm(N, l_tmpl);
       v = min2(v, car_follow_speed(speed, t, vL, tl, gap, interval));
     } else {
       v = min2(v, t.maxSpeed);
     }
     int nblk = -1;
-    bool related = is_link || (aux >= 0 && (L - dist) <= t.approach);
-    if (related) {
+    if (C.ablate & 1) {
+    } else if (IS_LINK) {
       double s = t.maxSpeed;
-      int link = is_link ? d : aux;
-      int k = link - N.n_lanes;
-      int ag = is_link ? my_agent : N.link_agent[k];
-      int raw = S.raw_phase[IDX(ag)];
-      bool done = false;
-      if (!is_link) {
-        bool avail = (N.link_avail_mask[k] >> raw) & 1u;
-        int e = N.link_end_lane[k];
-        int he = S.cnt[IDX(e)];
-        bool can_enter;
-        if ((he & TSC_CNT_MASK) == 0) can_enter = true;
-        else if (he & TSC_NEW_BIT) can_enter = false; // tail is a vehicle inserted this step: dist 0, speed 0
-        else {
-          int ttag = S.tail_tag[IDX(e)];
-          int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
-          can_enter = S.tail_dist[IDX(e)] > N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN] + t.len ||
-                      S.tail_speed[IDX(e)] >= 2;
-        }
-        if (!avail || !can_enter) {
-          if (min_brake_distance(speed, t) > L - dist) {
-            // cannot brake before the stop line
-          } else {
-            s = min2(s, stop_before_speed(speed, t, L - dist, interval));
-            done = true;
-          }
-        }
-        if (!done && N.link_type[k] != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
-      }
-      if (!done) {
-        unsigned long long oe = S.occ_e[IDX(ag)], ov = S.occ_v[IDX(ag)], os = S.occ_s[IDX(ag)];
-        unsigned long long active = N.link_conflict[k] & (oe | ov | os);
-        if (active) {
-          double distanceToLaneLinkStart = is_link ? dist : -(L - dist);
-          int ell = is_link ? aux : 0x7fffffff;
-          for (int e = N.link_cross_ptr[k]; e < N.link_cross_ptr[k + 1]; e++) {
-            double x = N.cross_dist_self[e];
-            if (x < distanceToLaneLinkStart) continue;
-            int other = N.cross_other[e];
-            if (!((active >> N.link_local[other - N.n_lanes]) & 1ull)) continue;
-            Foe f = find_foe<SINGLE>(N, S, r, vbase, other, N.cross_dist_other[e], oe, ov, os, raw);
-            if (!f.found) continue;
-            double d1 = x - distanceToLaneLinkStart;
-            if (!cross_can_pass(N, S, r, speed, t, vid, ell, link, other, d1, f, interval)) {
-              s = min2(s, stop_before_speed(speed, t, x - distanceToLaneLinkStart - t.yieldDist, interval));
-              nblk = f.vid;
-              break;
-            }
-          }
-        }
-      }
+      if (!(C.ablate & 16)) cross_scan<SINGLE>(N, S, r, vbase, d, true, speed, t, vid, aux, dist, oe, ov, os_green, interval, s, nblk, C.ablate);
       v = min2(v, s);
+    } else {
+      const bool related = aux >= 0 && (L - dist) <= t.approach;
+      if (__builtin_amdgcn_ballot_w64(related)) {
+        double s = t.maxSpeed;
+        for (int q = qb; q < qe; q++) {
+          const int link = N.lane_out_links[q];
+          const int k = link - N.n_lanes;
+          const bool mine = related && aux == link;
+          bool done = !mine;
+          if (mine && !(C.ablate & 32)) {
+            bool avail = (N.link_avail_mask[k] >> raw) & 1u;
+            const int e = N.link_end_lane[k];
+            int he = S.cnt[IDX(e)];
+            bool can_enter;
+            if ((he & TSC_CNT_MASK) == 0) can_enter = true;
+            else if (he & TSC_NEW_BIT) can_enter = false; // tail is a vehicle inserted this step: dist 0, speed 0
+            else {
+              int ttag = S.tail_tag[IDX(e)];
+              int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+              can_enter = S.tail_dist[IDX(e)] > N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN] + t.len ||
+                          S.tail_speed[IDX(e)] >= 2;
+            }
+            if (!avail || !can_enter) {
+              if (min_brake_distance(speed, t) > L - dist) {
+                // cannot brake before the stop line
+              } else {
+                s = min2(s, stop_before_speed(speed, t, L - dist, interval));
+                done = true;
+              }
+            }
+            if (!done && N.link_type[k] != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
+          }
+          if (!(C.ablate & 16))
+            cross_scan<SINGLE>(N, S, r, vbase, link, !done, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green, interval,
+                               s, nblk, C.ablate);
+        }
+        if (related) v = min2(v, s);
+      }
     }
     v = max2(v, speed - t.maxNegAcc * interval);
     double deltaDis;
@@ -458,27 +540,28 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
     } else {
       deltaDis = (speed + v) * interval / 2;
     }
+    // ---- blocker bookkeeping: slot word in place, vid-indexed entry in the other half
+    int old_b = TSC_BLK_VID(blkw);
+    int new_w = ((nblk + 1) & 0xffffff) | ((old_b >= 0) ? (1 << 30) : 0);
+    if (new_w != blkw) S.blk[SIDX(sb + i)] = new_w;
+    if (nblk >= 0 || old_b >= 0 || TSC_BLK_OLDER(blkw)) S.nbbv[IDX(vid)] = nblk;
     // ---- move (engine: setDeltaDistance)
     double nd = deltaDis + dist;
-    int fl = 0;
     if (nd > L) {
       nd -= L;
-      fl = TSC_F_MOVED;
-      if (!is_link && aux < 0) fl = TSC_F_MOVED | TSC_F_ENDED;
-      else if (!is_link && nd > N.drv_length[aux]) atomicAdd(&S.errors[3], 1); // double hand-off: unsupported
       if (n_out < TSC_OB_MAX) {
         ob |= (i & 1023) << (2 + 10 * n_out);
         size_t ox = ((size_t)d * TSC_OB_MAX + n_out) * (size_t)S.RS + (size_t)r;
         S.obx_tag[ox] = tag;
-        S.obx_aux[ox] = aux;
-        S.obx_blk[ox] = S.blk[IDX(sb + i)];
+        S.obx_aux[ox] = aux; // lane vehicle with aux < 0: leaves the network
+        S.obx_blk[ox] = new_w;
+        S.obx_dist[ox] = nd;
+        S.obx_speed[ox] = v;
       } else atomicAdd(&S.errors[1], 1);
       n_out++;
     }
-    S.ndist[IDX(sb + i)] = nd;
-    S.nspeed[IDX(sb + i)] = v;
-    S.nblk[IDX(sb + i)] = nblk;
-    S.nflag[IDX(sb + i)] = (unsigned char)fl;
+    o_dist[SIDX(sb + i)] = nd;
+    o_speed[SIDX(sb + i)] = v;
     p_dist = dist;
     p_speed = speed;
     p_tmpl = tid;
@@ -486,10 +569,86 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
   S.ob[IDX(d)] = ob | (n_out < TSC_OB_MAX ? n_out : TSC_OB_MAX);
 }
 
+// ----------------------------------------------------------------- k_follow
+// Plain followers on lanes (not the head, not within the approach distance of
+// the lane end): car-following behind the previous vehicle of the list only --
+// no signal, no crosses, no hand-off (they cannot reach the lane end within one
+// sub-step).  Small register footprint -> 8 waves per SIMD; this is where most
+// vehicles are.
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_follow(DevNet N, DevState S, DevCfg C, int n_rb, int n_lblk) {
+  int rb, lblk;
+  if (!map_block(n_rb, n_lblk, rb, lblk)) return;
+  int d = __builtin_amdgcn_readfirstlane(lblk * (int)blockDim.y + (int)threadIdx.y);
+  int r = rb * 64 + threadIdx.x;
+  if (d >= N.n_lanes || r >= S.R) return;
+  const int n = S.cnt[IDX(d)] & TSC_CNT_MASK;
+  if (n < 2) return;
+  const double interval = C.interval;
+  const double L = N.drv_length[d];
+  const double drvMax = N.drv_max_speed[d];
+  const int sb = N.drv_slot_base[d];
+  const int vbase = SINGLE ? 0 : N.set_veh_ptr[S.set[r]];
+  const double *__restrict__ g_dist = S.dist;
+  const double *__restrict__ g_speed = S.speed;
+  const int *__restrict__ g_tag = S.tag;
+  double *__restrict__ o_dist = S.ndist;
+  double *__restrict__ o_speed = S.nspeed;
+  double p_dist = g_dist[SIDX(sb)], p_speed = g_speed[SIDX(sb)];
+  int p_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(g_tag[SIDX(sb)]));
+  double c_dist = g_dist[SIDX(sb + 1)], c_speed = g_speed[SIDX(sb + 1)];
+  int c_blk = S.blk[SIDX(sb + 1)];
+  int c_tag = SINGLE ? 0 : g_tag[SIDX(sb + 1)];
+  for (int i = 1; i < n; i++) {
+    const double dist = c_dist, speed = c_speed;
+    const int blkw = c_blk, tag0 = c_tag;
+    if (i + 1 < n) { // next slot's loads before this slot's stores
+      c_dist = g_dist[SIDX(sb + i + 1)];
+      c_speed = g_speed[SIDX(sb + i + 1)];
+      c_blk = S.blk[SIDX(sb + i + 1)];
+      if (!SINGLE) c_tag = g_tag[SIDX(sb + i + 1)];
+    }
+    const int tid = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tag0));
+    const Tm t = load_tm(N, tid);
+    if ((L - dist) <= t.approach) { // k_action's
+      if (i >= TSC_HSCAN) atomicAdd(&S.errors[3], 1);
+    } else {
+      const Tm tl = load_tm(N, p_tmpl);
+      double gap = p_dist - tl.len - dist;
+      double v = t.maxSpeed;
+      v = min2(v, speed + t.maxPosAcc * interval);
+      v = min2(v, drvMax);
+      v = min2(v, car_follow_speed(speed, t, p_speed, tl, gap, interval));
+      v = max2(v, speed - t.maxNegAcc * interval);
+      double deltaDis;
+      if (v < 0) {
+        deltaDis = 0.5 * speed * speed / t.maxNegAcc;
+        v = 0;
+      } else {
+        deltaDis = (speed + v) * interval / 2;
+      }
+      if (blkw != 0) { // a blocker from its time near the previous intersection: let it expire
+        int old_b = TSC_BLK_VID(blkw);
+        int new_w = (old_b >= 0) ? (1 << 30) : 0;
+        S.blk[SIDX(sb + i)] = new_w;
+        S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + i)]))] = -1;
+      }
+      double nd = deltaDis + dist;
+      if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
+      o_dist[SIDX(sb + i)] = nd;
+      o_speed[SIDX(sb + i)] = v;
+    }
+    p_dist = dist;
+    p_speed = speed;
+    p_tmpl = tid;
+  }
+}
+
 // ---------------------------------------------------------------- k_commit
 template <bool SINGLE>
-__device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S, int r, int d, int sb, int t_next,
-                                             int &w, bool have_tail, double tail_dist, int tail_tmpl, int &has_new) {
+__device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S, double *q_dist, double *q_speed,
+                                             int r, int d, int sb, int t_next, int &w, bool have_tail,
+                                             double tail_dist, int tail_tmpl, int &has_new) {
   int set = S.set[r];
   int qb = N.spawn_ptr[set * N.n_lanes + d], qe = N.spawn_ptr[set * N.n_lanes + d + 1];
   if (qb == qe) return;
@@ -510,12 +669,13 @@ __device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S,
   }
   int route = N.veh_route[vbase + vid];
   int rb_ = N.route_ptr[route], re_ = N.route_ptr[route + 1];
-  S.dist[IDX(sb + w)] = 0;
-  S.speed[IDX(sb + w)] = 0;
-  S.tag[IDX(sb + w)] = TSC_MAKE_TAG(vid, 0);
-  S.aux[IDX(sb + w)] = (rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1;
-  S.blk[IDX(sb + w)] = -1;
-  S.blocker_by_vid[IDX(vid)] = -1;
+  q_dist[SIDX(sb + w)] = 0;
+  q_speed[SIDX(sb + w)] = 0;
+  S.tag[SIDX(sb + w)] = TSC_MAKE_TAG(vid, 0);
+  S.aux[SIDX(sb + w)] = (rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1;
+  S.blk[SIDX(sb + w)] = 0;
+  S.bbv[IDX(vid)] = -1;
+  S.nbbv[IDX(vid)] = -1;
   S.spawn_cur[IDX(d)] = c + 1;
   w++;
   has_new = 1;
@@ -531,42 +691,103 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   const bool is_link = d >= N.n_lanes;
   const int sb = N.drv_slot_base[d];
   const int cap = N.drv_cap[d];
-  const int t_now = S.t[r];
-  const int vbase = N.set_veh_ptr[S.set[r]];
+  // the half k_action just wrote: it becomes the committed state after this kernel
+  double *__restrict__ q_dist = S.ndist;
+  double *__restrict__ q_speed = S.nspeed;
   int hdr = S.cnt[IDX(d)];
   int n = hdr & TSC_CNT_MASK;
+  const int o_self = n > 0 ? S.ob[IDX(d)] : 0;
+  const int m_self = o_self & 3;
+  // ---- is anything arriving?
+  int fb, fe;
+  if (is_link) {
+    fb = 0;
+    fe = 1;
+  } else {
+    fb = N.lane_in_ptr[d];
+    fe = N.lane_in_ptr[d + 1];
+  }
+  bool arrivals = false;
+  for (int q = fb; q < fe; q++) {
+    int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
+    int o = S.ob[IDX(f)];
+    int m = o & 3;
+    for (int k = 0; k < m; k++) {
+      size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
+      int ax = S.obx_aux[ox];
+      if (is_link ? (ax == d) : true) arrivals = true;
+    }
+  }
+  const int t_now = S.t[r];
+  bool spawn_possible = false;
+  if (!is_link) {
+    int set = S.set[r];
+    int qb = N.spawn_ptr[set * N.n_lanes + d], qe = N.spawn_ptr[set * N.n_lanes + d + 1];
+    if (qb != qe) {
+      int c = S.spawn_cur[IDX(d)];
+      if (qb + c < qe && N.veh_start[N.set_veh_ptr[set] + N.spawn_vid[qb + c]] <= t_now + 1) spawn_possible = true;
+    }
+  }
+  if (m_self == 0 && !arrivals && !spawn_possible) {
+    // quiet drivable: only the tail record moves (and the inserted-this-step bit clears)
+    if (n > 0) {
+      S.tail_dist[IDX(d)] = q_dist[SIDX(sb + n - 1)];
+      S.tail_speed[IDX(d)] = q_speed[SIDX(sb + n - 1)];
+      if (hdr & TSC_NEW_BIT) {
+        S.tail_tag[IDX(d)] = S.tag[SIDX(sb + n - 1)];
+        S.tail_prev[IDX(d)] = -1;
+        S.cnt[IDX(d)] = n;
+      }
+    }
+    return;
+  }
+  const int vbase = N.set_veh_ptr[S.set[r]];
   int tp = (hdr & TSC_NEW_BIT) ? -1 : S.tail_prev[IDX(d)];
   // ---- keep / retire
+  const int s0 = m_self > 0 ? ((o_self >> 2) & 1023) : -1;
+  const int s1 = m_self > 1 ? ((o_self >> 12) & 1023) : -1;
+  const int s2 = m_self > 2 ? ((o_self >> 22) & 1023) : -1;
+  for (int k = 0; k < m_self; k++) {
+    size_t ox = ((size_t)d * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
+    if (!is_link && S.obx_aux[ox] < 0) { // left the network
+      int vid = TSC_TAG_VID(S.obx_tag[ox]);
+      int st0 = N.veh_start[vbase + vid];
+      atomicAdd(&S.fin_cnt[r], 1);
+      atomicAdd(&S.fin_dsum[r], (unsigned long long)(t_now - st0));
+      atomicAdd(&S.fin_ssum[r], (unsigned long long)st0);
+    }
+  }
   int w = 0;
   bool have_tail = false, old_tail_kept = false;
   double tl_dist = 0, tl_speed = 0;
   int tl_tag = 0;
-  for (int i = 0; i < n; i++) {
-    int fl = S.nflag[IDX(sb + i)];
-    if (fl == 0) {
-      double nd = S.ndist[IDX(sb + i)], ns = S.nspeed[IDX(sb + i)];
-      int tg = S.tag[IDX(sb + i)];
-      int ob_ = S.blk[IDX(sb + i)], nb = S.nblk[IDX(sb + i)];
-      S.dist[IDX(sb + w)] = nd;
-      S.speed[IDX(sb + w)] = ns;
+  if (m_self == 0) {
+    w = n;
+    if (n > 0) {
+      have_tail = true;
+      old_tail_kept = true;
+      tl_dist = q_dist[SIDX(sb + n - 1)];
+      tl_speed = q_speed[SIDX(sb + n - 1)];
+      tl_tag = S.tag[SIDX(sb + n - 1)];
+    }
+  } else {
+    for (int i = 0; i < n; i++) {
+      if (i == s0 || i == s1 || i == s2) continue;
+      double nd = q_dist[SIDX(sb + i)], ns = q_speed[SIDX(sb + i)];
+      int tg = S.tag[SIDX(sb + i)];
       if (w != i) {
-        S.tag[IDX(sb + w)] = tg;
-        S.aux[IDX(sb + w)] = S.aux[IDX(sb + i)];
+        q_dist[SIDX(sb + w)] = nd;
+        q_speed[SIDX(sb + w)] = ns;
+        S.tag[SIDX(sb + w)] = tg;
+        S.aux[SIDX(sb + w)] = S.aux[SIDX(sb + i)];
+        S.blk[SIDX(sb + w)] = S.blk[SIDX(sb + i)];
       }
-      S.blk[IDX(sb + w)] = nb;
-      if (ob_ != nb) S.blocker_by_vid[IDX(TSC_TAG_VID(tg))] = nb; // slot copy mirrors the vid-indexed entry
       have_tail = true;
       tl_dist = nd;
       tl_speed = ns;
       tl_tag = tg;
       old_tail_kept = (i == n - 1);
       w++;
-    } else if (fl & TSC_F_ENDED) {
-      int vid = TSC_TAG_VID(S.tag[IDX(sb + i)]);
-      int st0 = N.veh_start[vbase + vid];
-      atomicAdd(&S.fin_cnt[r], 1);
-      atomicAdd(&S.fin_dsum[r], (unsigned long long)(t_now - st0));
-      atomicAdd(&S.fin_ssum[r], (unsigned long long)st0);
     }
   }
   if (!have_tail) tp = -1;
@@ -577,77 +798,65 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     int route = N.veh_route[vbase + vid];
     tp = seq > 0 ? N.route_drv[N.route_ptr[route] + seq - 1] : -1;
   }
-  // ---- pull newcomers from feeder drivables, in descending buffered distance
-  int fb, fe;
-  if (is_link) {
-    fb = 0;
-    fe = 1;
-  } else {
-    fb = N.lane_in_ptr[d];
-    fe = N.lane_in_ptr[d + 1];
-  }
-  double last_nd = 1e300;
-  int last_vid = -1;
-  for (int pass = 0; pass < 16; pass++) {
-    double best_nd = -1e300;
-    int best_vid = 0x7fffffff, best_f = -1, best_s = -1, best_k = 0;
-    for (int q = fb; q < fe; q++) {
-      int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
-      int o = S.ob[IDX(f)];
-      int m = o & 3;
-      int fsb = N.drv_slot_base[f];
-      for (int k = 0; k < m; k++) {
-        int s = (o >> (2 + 10 * k)) & 1023;
-        size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
-        if (S.nflag[IDX(fsb + s)] & TSC_F_ENDED) continue;
-        if (is_link && S.obx_aux[ox] != d) continue;
-        double nd = S.ndist[IDX(fsb + s)];
-        int vid = TSC_TAG_VID(S.obx_tag[ox]);
-        bool after_last = nd < last_nd || (nd == last_nd && vid > last_vid);
-        bool before_best = nd > best_nd || (nd == best_nd && vid < best_vid);
-        if (after_last && before_best) {
-          best_nd = nd;
-          best_vid = vid;
-          best_f = f;
-          best_s = s;
-          best_k = k;
+  // ---- pull newcomers from feeder outboxes, in descending buffered distance
+  if (arrivals) {
+    double last_nd = 1e300;
+    int last_vid = -1;
+    for (int pass = 0; pass < 16; pass++) {
+      double best_nd = -1e300;
+      int best_vid = 0x7fffffff, best_f = -1;
+      size_t best_ox = 0;
+      for (int q = fb; q < fe; q++) {
+        int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
+        int o = S.ob[IDX(f)];
+        int m = o & 3;
+        for (int k = 0; k < m; k++) {
+          size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
+          int ax = S.obx_aux[ox];
+          if (is_link && ax != d) continue; // lanes: every leaver of a feeder link comes here
+          double nd = S.obx_dist[ox];
+          int vid = TSC_TAG_VID(S.obx_tag[ox]);
+          bool after_last = nd < last_nd || (nd == last_nd && vid > last_vid);
+          bool before_best = nd > best_nd || (nd == best_nd && vid < best_vid);
+          if (after_last && before_best) {
+            best_nd = nd;
+            best_vid = vid;
+            best_f = f;
+            best_ox = ox;
+          }
         }
       }
+      if (best_f < 0) break;
+      last_nd = best_nd;
+      last_vid = best_vid;
+      if (w >= cap) {
+        atomicAdd(&S.errors[0], 1);
+        break;
+      }
+      int tg = S.obx_tag[best_ox];
+      int seq = TSC_TAG_SEQ(tg) + 1;
+      double ns = S.obx_speed[best_ox];
+      int ntag = TSC_MAKE_TAG(best_vid, seq);
+      int naux;
+      if (is_link) {
+        naux = t_now; // enterLaneLinkTime
+      } else {
+        int route = N.veh_route[vbase + best_vid];
+        int pb = N.route_ptr[route], pe = N.route_ptr[route + 1];
+        naux = (pb + seq + 1 < pe) ? N.route_drv[pb + seq + 1] : -1;
+      }
+      q_dist[SIDX(sb + w)] = best_nd;
+      q_speed[SIDX(sb + w)] = ns;
+      S.tag[SIDX(sb + w)] = ntag;
+      S.aux[SIDX(sb + w)] = naux;
+      S.blk[SIDX(sb + w)] = S.obx_blk[best_ox];
+      have_tail = true;
+      tl_dist = best_nd;
+      tl_speed = ns;
+      tl_tag = ntag;
+      tp = is_link ? -1 : best_f;
+      w++;
     }
-    if (best_f < 0) break;
-    last_nd = best_nd;
-    last_vid = best_vid;
-    if (w >= cap) {
-      atomicAdd(&S.errors[0], 1);
-      break;
-    }
-    int fsb = N.drv_slot_base[best_f];
-    size_t box = ((size_t)best_f * TSC_OB_MAX + best_k) * (size_t)S.RS + (size_t)r;
-    int tg = S.obx_tag[box];
-    int seq = TSC_TAG_SEQ(tg) + 1;
-    int ob_ = S.obx_blk[box], nb = S.nblk[IDX(fsb + best_s)];
-    double ns = S.nspeed[IDX(fsb + best_s)];
-    int ntag = TSC_MAKE_TAG(best_vid, seq);
-    int naux;
-    if (is_link) {
-      naux = t_now; // enterLaneLinkTime
-    } else {
-      int route = N.veh_route[vbase + best_vid];
-      int pb = N.route_ptr[route], pe = N.route_ptr[route + 1];
-      naux = (pb + seq + 1 < pe) ? N.route_drv[pb + seq + 1] : -1;
-    }
-    S.dist[IDX(sb + w)] = best_nd;
-    S.speed[IDX(sb + w)] = ns;
-    S.tag[IDX(sb + w)] = ntag;
-    S.aux[IDX(sb + w)] = naux;
-    S.blk[IDX(sb + w)] = nb;
-    if (ob_ != nb) S.blocker_by_vid[IDX(best_vid)] = nb;
-    have_tail = true;
-    tl_dist = best_nd;
-    tl_speed = ns;
-    tl_tag = ntag;
-    tp = is_link ? -1 : best_f;
-    w++;
   }
   // ---- tail record (the tail BEFORE the next step's insertion)
   if (have_tail) {
@@ -658,9 +867,9 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   S.tail_prev[IDX(d)] = tp;
   // ---- spawn for the next step (engine: flows + handleWaiting, appendix B.3)
   int has_new = 0;
-  if (!is_link) {
+  if (spawn_possible) {
     int tail_tmpl = have_tail ? tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tl_tag)) : 0;
-    spawn_if_due<SINGLE>(N, S, r, d, sb, t_now + 1, w, have_tail, tl_dist, tail_tmpl, has_new);
+    spawn_if_due<SINGLE>(N, S, q_dist, q_speed, r, d, sb, t_now + 1, w, have_tail, tl_dist, tail_tmpl, has_new);
   }
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
 }
@@ -681,7 +890,7 @@ __global__ __launch_bounds__(256) void k_reset(DevNet N, DevState S, DevCfg C, c
   int w = 0, has_new = 0;
   if (d < N.n_lanes) {
     S.spawn_cur[IDX(d)] = 0;
-    spawn_if_due<SINGLE>(N, S, r, d, N.drv_slot_base[d], 0, w, false, 0.0, 0, has_new);
+    spawn_if_due<SINGLE>(N, S, S.dist, S.speed, r, d, N.drv_slot_base[d], 0, w, false, 0.0, 0, has_new);
   }
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
 }
@@ -783,8 +992,8 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
   for (int i = 0; i < n; i++) {
-    double dist = S.dist[IDX(sb + i)];
-    double speed = S.speed[IDX(sb + i)];
+    double dist = S.dist[SIDX(sb + i)];
+    double speed = S.speed[SIDX(sb + i)];
     if (speed < 0.1) q++;
     sum += speed;
     if (bins > 0) {
@@ -843,12 +1052,12 @@ __global__ void k_posmat(DevNet N, DevState S, DevCfg C, double *posmat, int max
   if (bins <= 0) return;
   double bin_size = len / bins;
   for (int i = 0; i < n; i++) {
-    double pos = round6(S.dist[IDX(sb + i)]);
+    double pos = round6(S.dist[SIDX(sb + i)]);
     if (pos < 0) pos = 0;
     else if (pos > len) pos = len;
     int idx = (int)py_floordiv(pos, bin_size);
     if (idx >= bins) idx = bins - 1;
-    double norm_speed = round6(S.speed[IDX(sb + i)]) / maxspd;
+    double norm_speed = round6(S.speed[SIDX(sb + i)]) / maxspd;
     pm[idx] += 1.0;
     pm[idx] += norm_speed;
   }
@@ -1148,9 +1357,9 @@ __global__ void k_snapshot(DevNet N, DevState S, int rep, int cap, int *count, i
     if (k < cap) {
       drv[k] = d;
       slot[k] = i;
-      dist[k] = S.dist[IDX(sb + i)];
-      speed[k] = S.speed[IDX(sb + i)];
-      vid[k] = TSC_TAG_VID(S.tag[IDX(sb + i)]);
+      dist[k] = S.dist[SIDX(sb + i)];
+      speed[k] = S.speed[SIDX(sb + i)];
+      vid[k] = TSC_TAG_VID(S.tag[SIDX(sb + i)]);
     }
   }
 }

@@ -1,0 +1,23 @@
+"""Diagnostic: price the parts of k_action on a frozen, congested state."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import workload_tables
+from pytsc_amd.vec_env import VecEngine
+
+tables = workload_tables(4, 4, 4096, 0, 700.0, 8)
+eng = VecEngine(tables, want=("mask",))
+buf = eng.observe()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+u = torch.empty((4096, 16, 16), device="cuda")
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 150):
+    u.uniform_(1e-6, 1.0, generator=g)
+    buf = eng.step((u * buf["mask"]).argmax(-1).to(torch.int32))
+print("vehicles/replica", eng.mean_vehicles())
+eng.lib.tsc_debug_time_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+ms = C.c_double()
+for which, name in ((8, "notify"), (16, "follow"), (1, "lanes"), (2, "links")):
+    for ab in ((0,) if which in (4, 8, 16) else (0, 128, 16)):
+        eng.lib.tsc_debug_time_action(eng.h, ab, which, 5, C.byref(ms))
+        print(name, "ablate", ab, "us", round(ms.value * 1e3, 1))
