@@ -334,30 +334,52 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
   }
 }
 
-// One wavefront = 64 replicas of ONE drivable: every static-table access below is
-// wave-uniform (scalar), every state access is coalesced along the replica axis.
-// For lanes the per-vehicle choice of the next lane-link (`aux`) differs between
-// replicas, so the code iterates over the lane's (<= 3) outgoing links with a
-// wave-uniform loop and lets each replica act in the iteration of its own link.
+// ------------------------------------------------------------------ k_drive
+// One workgroup = ONE wavefront = 64 replicas of ONE drivable, in two roles:
+//  (1) enumeration: lane l walks the slots of ITS replica (coalesced loads along
+//      the replica axis, wave-uniform topology) and classifies every vehicle:
+//        - plain follower that is stopped in a stopped queue  -> result is known
+//          without arithmetic (v = 0, position unchanged), stored at once;
+//        - plain follower (not the head, not within the approach distance of the
+//          lane end)                                            -> queue F in LDS;
+//        - head / near the lane end / on a lane-link           -> queue H in LDS;
+//  (2) execution: whenever a queue holds 64 work items, the 64 lanes each take one
+//      item (whatever replica and slot it came from) and run the car-following /
+//      intersection logic with all lanes busy.
+// Replicas hold very different numbers of vehicles, so walking slots in lock-step
+// leaves most lanes idle (23 % of VALU lanes active in the v1 kernel); the
+// engine's update is Jacobi (every decision reads only committed state), so
+// vehicles can be executed in any grouping.  Items of a batch come from
+// neighbouring replicas of the same drivable: their global accesses stay within
+// the same few 512-byte rows.  The execution stage issues its loads in groups
+// (item + leader slot; headers of the out-links and of the own end lane) so that a
+// batch costs a few memory round trips instead of one per dependent lookup.
+#define TSC_QCAP 256
+#define TSC_QMASK (TSC_QCAP - 1)
+#define TSC_MAXQ 4 /* out-links of a lane (checked at create): one H queue per out-link */
+#define TSC_NQ (TSC_MAXQ + 1)
+#define TSC_QF TSC_MAXQ /* queue of plain followers */
+
+struct DriveShared {
+  int meta[TSC_NQ][TSC_QCAP]; // (replica within block << 16) | slot
+  unsigned long long oe[64], ov[64], osg[64];
+  int raw[64], vbase[64], ob_cnt[64], ob_slot[64][TSC_OB_MAX];
+};
+
 template <bool SINGLE, bool IS_LINK>
-__global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, int n_rb, int n_dblk) {
-  int rb, dblk;
-  if (!map_block(n_rb, n_dblk, rb, dblk)) return;
-  int row = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
-  int r = rb * 64 + threadIdx.x;
-  if (row >= (IS_LINK ? N.n_links : N.n_lanes) || r >= S.R) return;
+__global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+  __shared__ DriveShared sh;
+  int rb, row;
+  if (!map_block(n_rb, n_rows, rb, row)) return;
+  row = __builtin_amdgcn_readfirstlane(row);
+  const int lane = threadIdx.x;
+  const int r_own = rb * 64 + lane;
+  const bool own_valid = r_own < S.R;
   const int d = IS_LINK ? N.n_lanes + row : row;
-  int hdr = S.cnt[IDX(d)];
-  int n = hdr & TSC_CNT_MASK;
-  if (n == 0) {
-    S.ob[IDX(d)] = 0;
-    return;
-  }
   const double interval = C.interval;
   const double L = N.drv_length[d];
   const double drvMax = N.drv_max_speed[d];
   const int sb = N.drv_slot_base[d];
-  const int vbase = SINGLE ? 0 : N.set_veh_ptr[S.set[r]];
   const int end_lane = IS_LINK ? N.link_end_lane[row] : -1;
   const int qb = IS_LINK ? 0 : N.lane_out_ptr[d], qe = IS_LINK ? 0 : N.lane_out_ptr[d + 1];
   // the signal that owns this lane's end / this link (wave-uniform); -1: lane ends at a virtual node
@@ -369,152 +391,352 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
   double *__restrict__ o_dist = S.ndist;
   double *__restrict__ o_speed = S.nspeed;
 
-  int raw = 0;
-  unsigned long long oe = 0, ov = 0, os_green = 0; // cross candidates of this intersection (k_notify)
-  if (ag >= 0) {
-    raw = S.raw_phase[IDX(ag)];
-    oe = S.occ_e[IDX(ag)];
-    ov = S.occ_v[IDX(ag)];
-    // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
-    os_green = S.occ_s[IDX(ag)] & N.agent_phase_avail[(size_t)ag * 32 + raw];
+  int n = 0;
+  {
+    const int r = own_valid ? r_own : 0;
+    if (own_valid) n = S.cnt[IDX(d)] & TSC_CNT_MASK;
+    int raw = 0;
+    unsigned long long oe = 0, ov = 0, osg = 0;
+    if (ag >= 0 && n > 0) {
+      raw = S.raw_phase[IDX(ag)];
+      oe = S.occ_e[IDX(ag)];
+      ov = S.occ_v[IDX(ag)];
+      // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
+      osg = S.occ_s[IDX(ag)] & N.agent_phase_avail[(size_t)ag * 32 + raw];
+    }
+    sh.raw[lane] = raw;
+    sh.oe[lane] = oe;
+    sh.ov[lane] = ov;
+    sh.osg[lane] = osg;
+    sh.vbase[lane] = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
+    sh.ob_cnt[lane] = 0;
   }
+  if (!__builtin_amdgcn_ballot_w64(n > 0)) { // nothing on this drivable in any of the 64 replicas
+    if (own_valid) {
+      const int r = r_own;
+      S.ob[IDX(d)] = 0;
+    }
+    return;
+  }
+  __syncthreads();
 
+  // loop invariants of the enumeration, hoisted by hand (the compiler must assume the
+  // stores inside the loop may alias the tables)
+  int olk[TSC_MAXQ];
+#pragma unroll
+  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (!IS_LINK && qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
+  const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
+  // wave-uniform queue state: H queues [0, TSC_MAXQ) -- lanes: one per out-link, so that
+  // a batch deals with ONE lane-link (uniform cross table, coalesced header loads);
+  // links and vehicles without a next link use queue 0 -- and the follower queue TSC_QF
+  int head[TSC_NQ], count[TSC_NQ];
+#pragma unroll
+  for (int q = 0; q < TSC_NQ; q++) head[q] = count[q] = 0;
   double p_dist = 0, p_speed = 0;
   int p_tmpl = 0;
-  int ob = 0, n_out = 0;
-  // software pipeline: the next slot's loads are issued before this slot's stores
-  double c_dist = g_dist[SIDX(sb)], c_speed = g_speed[SIDX(sb)];
-  int c_tag = g_tag[SIDX(sb)], c_aux = g_aux[SIDX(sb)], c_blk = S.blk[SIDX(sb)];
-  // Lanes: this kernel handles the head vehicle and the vehicles within the
-  // approach distance of the lane end (they form a prefix of the list, scanned up
-  // to TSC_HSCAN slots); every other vehicle is a plain follower and is advanced
-  // by k_follow with the same predicate.
-  const int n_scan = IS_LINK ? n : (n < TSC_HSCAN ? n : TSC_HSCAN);
-  for (int i = 0; i < n_scan; i++) {
-    const double dist = c_dist, speed = c_speed;
-    const int tag = c_tag, aux = c_aux, blkw = c_blk;
-    if (i + 1 < n_scan) {
-      c_dist = g_dist[SIDX(sb + i + 1)];
-      c_speed = g_speed[SIDX(sb + i + 1)];
-      c_tag = g_tag[SIDX(sb + i + 1)];
-      c_aux = g_aux[SIDX(sb + i + 1)];
-      c_blk = S.blk[SIDX(sb + i + 1)];
+  int i = 0;
+  bool more = true;
+  // software pipeline of the enumeration: two slots per turn, the next two in flight
+  double c_dist[2] = {0, 0}, c_speed[2] = {0, 0};
+  int c_blk[2] = {0, 0}, c_tag[2] = {0, 0}, c_aux[2] = {-1, -1};
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+    if (u < n) {
+      const int r = r_own;
+      c_dist[u] = g_dist[SIDX(sb + u)];
+      c_speed[u] = g_speed[SIDX(sb + u)];
+      c_blk[u] = S.blk[SIDX(sb + u)];
+      if (!IS_LINK) c_aux[u] = g_aux[SIDX(sb + u)];
+      if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + u)];
     }
-    int vid = TSC_TAG_VID(tag);
-    int tid = tmpl_of<SINGLE>(N, vbase, vid);
-    Tm t = load_tm(N, tid);
-    if (!IS_LINK && i > 0 && !((L - dist) <= t.approach)) { // a follower: k_follow's
-      p_dist = dist;
-      p_speed = speed;
-      p_tmpl = tid;
-      continue;
+  for (;;) {
+    int pick = -1;
+#pragma unroll
+    for (int q = 0; q < TSC_NQ; q++)
+      if (pick < 0 && count[q] >= 64) pick = q;
+    if (pick < 0 && !more) {
+#pragma unroll
+      for (int q = 0; q < TSC_NQ; q++)
+        if (pick < 0 && count[q] > 0) pick = q;
+      if (pick < 0) break;
     }
-
-    // ---- leader and gap (engine: updateLeaderAndGap)
-    bool has_leader = false;
-    double gap = 0, vL = 0;
-    int l_tmpl = 0;
-    if (i > 0) {
-      has_leader = true;
-      double plen = N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
-      gap = p_dist - plen - dist;
-      vL = p_speed;
-      l_tmpl = p_tmpl;
-    } else if (!(C.ablate & 2)) {
-      double dis = L - dist;
-      double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * interval * 2;
-      if (IS_LINK) {
-        int he = S.cnt[IDX(end_lane)];
-        int ne = (he & TSC_CNT_MASK) - ((he & TSC_NEW_BIT) ? 1 : 0); // tail before this step's insertion
-        if (ne > 0) {
-          int ttag = S.tail_tag[IDX(end_lane)];
-          int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
-          has_leader = true;
-          gap = dis + S.tail_dist[IDX(end_lane)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
-          vL = S.tail_speed[IDX(end_lane)];
-          l_tmpl = tt;
+    if (pick < 0) {
+      // ------------------------------------------------ (1) enumerate slots i, i+1
+      double dist2[2], speed2[2];
+      int blk2[2], tag2[2], aux2[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        dist2[u] = c_dist[u];
+        speed2[u] = c_speed[u];
+        blk2[u] = c_blk[u];
+        tag2[u] = c_tag[u];
+        aux2[u] = c_aux[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        if (i + 2 + u < n) {
+          const int r = r_own;
+          c_dist[u] = g_dist[SIDX(sb + i + 2 + u)];
+          c_speed[u] = g_speed[SIDX(sb + i + 2 + u)];
+          c_blk[u] = S.blk[SIDX(sb + i + 2 + u)];
+          if (!IS_LINK) c_aux[u] = g_aux[SIDX(sb + i + 2 + u)];
+          if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + 2 + u)];
         }
-      } else if (aux >= 0) {
-        // all lane-links leaving this lane may overlap: nearest tail wins
-        double my_len = 0;
-        for (int q = qb; q < qe; q++) {
-          const int ll = N.lane_out_links[q];
-          if (ll == aux) my_len = N.drv_length[ll];
-          int nl = S.cnt[IDX(ll)] & TSC_CNT_MASK;
-          if (nl > 0) {
-            int ttag = S.tail_tag[IDX(ll)];
-            int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
-            double cg = dis + S.tail_dist[IDX(ll)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
-            if (!has_leader || cg < gap) {
-              has_leader = true;
-              gap = cg;
-              vL = S.tail_speed[IDX(ll)];
-              l_tmpl = tt;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int is = i + u;
+        const bool active = is < n;
+        const double dist = dist2[u], speed = speed2[u];
+        const int blkw = blk2[u];
+        int tid = 0, bucket = -1;
+        if (active) {
+          tid = SINGLE ? 0 : N.veh_tmpl[sh.vbase[lane] + TSC_TAG_VID(tag2[u])];
+          const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
+          const bool heavy = IS_LINK || is == 0 || (L - dist) <= approach;
+          bucket = TSC_QF;
+          if (heavy) {
+            bucket = 0;
+            if (!IS_LINK) {
+#pragma unroll
+              for (int qq = 1; qq < TSC_MAXQ; qq++)
+                if (olk[qq] == aux2[u]) bucket = qq;
+            }
+          }
+          if (!IS_LINK && is > 0 && speed == 0 && p_speed == 0) {
+            // A lane vehicle stopped behind a stopped leader within minGap: both
+            // no-collision bounds are negative whatever the signal or the crosses say, so
+            // v = 0 and the position is unchanged -- no arithmetic needed.  (The blocker
+            // the engine would note for it is never read: only lane heads, vehicles on
+            // lane-links and fresh tails are ever registered at a cross.)
+            const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+            const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
+            if (p_dist - plen - dist <= mg) {
+              const int r = r_own;
+              bucket = -1;
+              if (blkw != 0) { // let an earlier blocker entry expire
+                S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+                S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
+              }
+              o_dist[SIDX(sb + is)] = dist;
+              o_speed[SIDX(sb + is)] = 0.0;
             }
           }
         }
-        if (!has_leader) {
-          dis += my_len;
-          if (!(dis > limit)) {
-            for (int q = qb; q < qe; q++) {
-              const int ll = N.lane_out_links[q];
-              const int el = N.link_end_lane[ll - N.n_lanes];
-              if (ll != aux) continue;
-              int he = S.cnt[IDX(el)];
-              int ne = (he & TSC_CNT_MASK) - ((he & TSC_NEW_BIT) ? 1 : 0);
-              if (ne > 0) {
-                int ttag = S.tail_tag[IDX(el)];
-                int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
+#pragma unroll
+        for (int q = 0; q < TSC_NQ; q++) {
+          if (IS_LINK && q != 0) continue;
+          if (!IS_LINK && q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
+          const bool put = bucket == q;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
+          if (m) {
+            const int rank =
+                __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (put) sh.meta[q][(head[q] + count[q] + rank) & TSC_QMASK] = (lane << 16) | is;
+            count[q] += __builtin_popcountll(m);
+          }
+        }
+        p_dist = dist;
+        p_speed = speed;
+        p_tmpl = tid;
+      }
+      i += 2;
+      more = __builtin_amdgcn_ballot_w64(i < n) != 0;
+      continue;
+    }
+    __syncthreads();
+    if (C.ablate & 256) {
+#pragma unroll
+      for (int q = 0; q < TSC_NQ; q++) count[q] = 0;
+      continue;
+    }
+    // pop one batch from queue `pick` (wave-uniform)
+    int nb = 0, meta = 0;
+#pragma unroll
+    for (int q = 0; q < TSC_NQ; q++)
+      if (q == pick) {
+        nb = count[q] < 64 ? count[q] : 64;
+        meta = sh.meta[q][(head[q] + lane) & TSC_QMASK];
+        head[q] = (head[q] + nb) & TSC_QMASK;
+        count[q] -= nb;
+      }
+    const bool valid = lane < nb;
+    const int rl = valid ? (meta >> 16) : lane; // replica of the item within this block
+    const int it = valid ? (meta & 0xffff) : 0;
+    const int r = rb * 64 + rl;
+    const int vbase = sh.vbase[rl];
+    if (pick == TSC_QF) {
+      // ------------------------------------------------ (2a) plain followers
+      if (valid) {
+        const double dist = g_dist[SIDX(sb + it)], speed = g_speed[SIDX(sb + it)];
+        const double pd = g_dist[SIDX(sb + it - 1)], vL = g_speed[SIDX(sb + it - 1)];
+        const int blkw = S.blk[SIDX(sb + it)];
+        int tid = 0, ptid = 0;
+        if (!SINGLE) {
+          tid = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + it)])];
+          ptid = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + it - 1)])];
+        }
+        const Tm t = load_tm(N, tid);
+        const Tm tl = load_tm(N, ptid);
+        const double gap = pd - tl.len - dist;
+        double v = t.maxSpeed;
+        v = min2(v, speed + t.maxPosAcc * interval);
+        v = min2(v, drvMax);
+        v = min2(v, car_follow_speed(speed, t, vL, tl, gap, interval));
+        v = max2(v, speed - t.maxNegAcc * interval);
+        double deltaDis;
+        if (v < 0) {
+          deltaDis = 0.5 * speed * speed / t.maxNegAcc;
+          v = 0;
+        } else {
+          deltaDis = (speed + v) * interval / 2;
+        }
+        if (blkw != 0) { // let a blocker from the previous intersection expire
+          S.blk[SIDX(sb + it)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+          S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + it)]))] = -1;
+        }
+        const double nd = deltaDis + dist;
+        if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
+        o_dist[SIDX(sb + it)] = nd;
+        o_speed[SIDX(sb + it)] = v;
+      }
+      __syncthreads();
+      continue;
+    }
+    // -------------------------------------------------- (2b) head / near the lane end / on a lane-link
+    {
+      // the lane-link this batch deals with (wave-uniform); lanes: out-link `pick`
+      const int link = IS_LINK ? d : (qb + pick < qe ? N.lane_out_links[qb + pick] : -1);
+      const int lk = link >= 0 ? link - N.n_lanes : 0;
+      const int el = IS_LINK ? end_lane : (link >= 0 ? N.link_end_lane[lk] : 0);
+      const int raw = sh.raw[rl];
+      const unsigned long long oe = sh.oe[rl], ov = sh.ov[rl], os_green = sh.osg[rl];
+      // ---- load group 0: the item and its list predecessor
+      double dist = 0, speed = 0, pd = 0, ps = 0;
+      int tag = 0, aux = -1, blkw = 0, ptag = 0;
+      if (valid) {
+        dist = g_dist[SIDX(sb + it)];
+        speed = g_speed[SIDX(sb + it)];
+        tag = g_tag[SIDX(sb + it)];
+        aux = g_aux[SIDX(sb + it)];
+        blkw = S.blk[SIDX(sb + it)];
+        if (it > 0) {
+          pd = g_dist[SIDX(sb + it - 1)];
+          ps = g_speed[SIDX(sb + it - 1)];
+          if (!SINGLE) ptag = g_tag[SIDX(sb + it - 1)];
+        }
+      }
+      // ---- load group 1: headers of the out-links (tails: look-ahead of a head vehicle)
+      //      and of the own link's end lane (look-ahead, canEnter) -- all independent
+      int l_cnt[TSC_MAXQ], l_tt[TSC_MAXQ];
+      double l_td[TSC_MAXQ], l_ts[TSC_MAXQ];
+      int e_hdr = 0, e_tt = 0;
+      double e_td = 0, e_ts = 0;
+      const bool has_link = IS_LINK ? false : (valid && aux >= 0); // then aux == link (bucketed)
+      if (IS_LINK ? (valid && it == 0) : has_link) {
+        e_hdr = S.cnt[IDX(el)];
+        e_td = S.tail_dist[IDX(el)];
+        e_ts = S.tail_speed[IDX(el)];
+        if (!SINGLE) e_tt = S.tail_tag[IDX(el)];
+      }
+      if (!IS_LINK) {
+#pragma unroll
+        for (int qq = 0; qq < TSC_MAXQ; qq++) {
+          l_cnt[qq] = 0;
+          l_tt[qq] = 0;
+          l_td[qq] = 0;
+          l_ts[qq] = 0;
+          if (qb + qq < qe && has_link && it == 0) {
+            const int ll = N.lane_out_links[qb + qq];
+            l_cnt[qq] = S.cnt[IDX(ll)] & TSC_CNT_MASK;
+            l_td[qq] = S.tail_dist[IDX(ll)];
+            l_ts[qq] = S.tail_speed[IDX(ll)];
+            if (!SINGLE) l_tt[qq] = S.tail_tag[IDX(ll)];
+          }
+        }
+      }
+      const double my_len = link >= 0 ? N.drv_length[link] : 0.0;
+      const int vid = TSC_TAG_VID(tag);
+      const int tid = tmpl_of<SINGLE>(N, vbase, vid);
+      const Tm t = load_tm(N, tid);
+      const int e_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(e_tt));
+      const double e_len = N.tmpl[(size_t)e_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+
+      // ---- leader and gap (engine: updateLeaderAndGap)
+      bool has_leader = false;
+      double gap = 0, vL = 0;
+      int l_tmpl = 0;
+      if (valid && it > 0) {
+        has_leader = true;
+        l_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ptag));
+        gap = pd - N.tmpl[(size_t)l_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN] - dist;
+        vL = ps;
+      } else if (valid) {
+        double dis = L - dist;
+        double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * interval * 2;
+        const int ne = (e_hdr & TSC_CNT_MASK) - ((e_hdr & TSC_NEW_BIT) ? 1 : 0); // tail before this step's insertion
+        if (IS_LINK) {
+          if (ne > 0) {
+            has_leader = true;
+            gap = dis + e_td - e_len;
+            vL = e_ts;
+            l_tmpl = e_tmpl;
+          }
+        } else if (has_link) {
+          // all lane-links leaving this lane may overlap: nearest tail wins
+#pragma unroll
+          for (int qq = 0; qq < TSC_MAXQ; qq++) {
+            if (qb + qq < qe && l_cnt[qq] > 0) {
+              int tt = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(l_tt[qq]));
+              double cg = dis + l_td[qq] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+              if (!has_leader || cg < gap) {
                 has_leader = true;
-                gap = dis + S.tail_dist[IDX(el)] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
-                vL = S.tail_speed[IDX(el)];
+                gap = cg;
+                vL = l_ts[qq];
                 l_tmpl = tt;
               }
+            }
+          }
+          if (!has_leader) {
+            dis += my_len;
+            if (!(dis > limit) && ne > 0) {
+              has_leader = true;
+              gap = dis + e_td - e_len;
+              vL = e_ts;
+              l_tmpl = e_tmpl;
               // beyond: a whole lane further is past the look-ahead limit (checked at create)
             }
           }
         }
       }
-    }
 
-    // ---- speed choice (engine: getNextSpeed)
-    double v = t.maxSpeed;
-    v = min2(v, speed + t.maxPosAcc * interval);
-    v = min2(v, drvMax);
-    if (has_leader && !(C.ablate & 4)) {
-      Tm tl = load_tm(N, l_tmpl);
-      v = min2(v, car_follow_speed(speed, t, vL, tl, gap, interval));
-    } else {
-      v = min2(v, t.maxSpeed);
-    }
-    int nblk = -1;
-    if (C.ablate & 1) {
-    } else if (IS_LINK) {
-      double s = t.maxSpeed;
-      if (!(C.ablate & 16)) cross_scan<SINGLE>(N, S, r, vbase, d, true, speed, t, vid, aux, dist, oe, ov, os_green, interval, s, nblk, C.ablate);
-      v = min2(v, s);
-    } else {
-      const bool related = aux >= 0 && (L - dist) <= t.approach;
-      if (__builtin_amdgcn_ballot_w64(related)) {
+      // ---- speed choice (engine: getNextSpeed)
+      double v = t.maxSpeed;
+      v = min2(v, speed + t.maxPosAcc * interval);
+      v = min2(v, drvMax);
+      if (has_leader) {
+        Tm tl = load_tm(N, l_tmpl);
+        v = min2(v, car_follow_speed(speed, t, vL, tl, gap, interval));
+      } else {
+        v = min2(v, t.maxSpeed);
+      }
+      int nblk = -1;
+      if (IS_LINK) {
         double s = t.maxSpeed;
-        for (int q = qb; q < qe; q++) {
-          const int link = N.lane_out_links[q];
-          const int k = link - N.n_lanes;
-          const bool mine = related && aux == link;
-          bool done = !mine;
-          if (mine && !(C.ablate & 32)) {
-            bool avail = (N.link_avail_mask[k] >> raw) & 1u;
-            const int e = N.link_end_lane[k];
-            int he = S.cnt[IDX(e)];
+        if (!(C.ablate & 16))
+          cross_scan<SINGLE>(N, S, r, vbase, d, valid, speed, t, vid, aux, dist, oe, ov, os_green, interval, s, nblk,
+                             C.ablate);
+        v = min2(v, s);
+      } else {
+        const bool related = has_link && (L - dist) <= t.approach && !(C.ablate & 1);
+        if (__builtin_amdgcn_ballot_w64(related)) {
+          double s = t.maxSpeed;
+          bool done = !related;
+          if (related) {
+            const bool avail = (N.link_avail_mask[lk] >> raw) & 1u;
             bool can_enter;
-            if ((he & TSC_CNT_MASK) == 0) can_enter = true;
-            else if (he & TSC_NEW_BIT) can_enter = false; // tail is a vehicle inserted this step: dist 0, speed 0
-            else {
-              int ttag = S.tail_tag[IDX(e)];
-              int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
-              can_enter = S.tail_dist[IDX(e)] > N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN] + t.len ||
-                          S.tail_speed[IDX(e)] >= 2;
-            }
+            if ((e_hdr & TSC_CNT_MASK) == 0) can_enter = true;
+            else if (e_hdr & TSC_NEW_BIT) can_enter = false; // tail is a vehicle inserted this step: dist 0, speed 0
+            else can_enter = e_td > e_len + t.len || e_ts >= 2;
             if (!avail || !can_enter) {
               if (min_brake_distance(speed, t) > L - dist) {
                 // cannot brake before the stop line
@@ -523,102 +745,27 @@ __global__ __launch_bounds__(256) void k_action(DevNet N, DevState S, DevCfg C, 
                 done = true;
               }
             }
-            if (!done && N.link_type[k] != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
+            if (!done && N.link_type[lk] != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
+          }
+          // A non-head vehicle whose first cross lies beyond its braking distance after one
+          // more acceleration step cannot be slowed by any cross (stop_before_speed would
+          // return speed + maxPosAcc*dt, already a bound of v), and its blocker is never read
+          // (see the enumeration note): the scan is skipped.  Heads are always scanned.
+          bool scan = !done;
+          if (scan && it > 0 && link >= 0) {
+            const int cb = N.link_cross_ptr[lk];
+            if (cb < N.link_cross_ptr[lk + 1]) {
+              const double nextSpeed = speed + t.maxPosAcc * interval;
+              const double bd = (speed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / t.usualNegAcc / 2);
+              if (bd < N.cross_rec[cb].x + (L - dist) - t.yieldDist) scan = false;
+            } else scan = false;
           }
           if (!(C.ablate & 16))
-            cross_scan<SINGLE>(N, S, r, vbase, link, !done, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green, interval,
-                               s, nblk, C.ablate);
+            cross_scan<SINGLE>(N, S, r, vbase, link, scan, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green,
+                               interval, s, nblk, C.ablate);
+          if (related) v = min2(v, s);
         }
-        if (related) v = min2(v, s);
       }
-    }
-    v = max2(v, speed - t.maxNegAcc * interval);
-    double deltaDis;
-    if (v < 0) {
-      deltaDis = 0.5 * speed * speed / t.maxNegAcc;
-      v = 0;
-    } else {
-      deltaDis = (speed + v) * interval / 2;
-    }
-    // ---- blocker bookkeeping: slot word in place, vid-indexed entry in the other half
-    int old_b = TSC_BLK_VID(blkw);
-    int new_w = ((nblk + 1) & 0xffffff) | ((old_b >= 0) ? (1 << 30) : 0);
-    if (new_w != blkw) S.blk[SIDX(sb + i)] = new_w;
-    if (nblk >= 0 || old_b >= 0 || TSC_BLK_OLDER(blkw)) S.nbbv[IDX(vid)] = nblk;
-    // ---- move (engine: setDeltaDistance)
-    double nd = deltaDis + dist;
-    if (nd > L) {
-      nd -= L;
-      if (n_out < TSC_OB_MAX) {
-        ob |= (i & 1023) << (2 + 10 * n_out);
-        size_t ox = ((size_t)d * TSC_OB_MAX + n_out) * (size_t)S.RS + (size_t)r;
-        S.obx_tag[ox] = tag;
-        S.obx_aux[ox] = aux; // lane vehicle with aux < 0: leaves the network
-        S.obx_blk[ox] = new_w;
-        S.obx_dist[ox] = nd;
-        S.obx_speed[ox] = v;
-      } else atomicAdd(&S.errors[1], 1);
-      n_out++;
-    }
-    o_dist[SIDX(sb + i)] = nd;
-    o_speed[SIDX(sb + i)] = v;
-    p_dist = dist;
-    p_speed = speed;
-    p_tmpl = tid;
-  }
-  S.ob[IDX(d)] = ob | (n_out < TSC_OB_MAX ? n_out : TSC_OB_MAX);
-}
-
-// ----------------------------------------------------------------- k_follow
-// Plain followers on lanes (not the head, not within the approach distance of
-// the lane end): car-following behind the previous vehicle of the list only --
-// no signal, no crosses, no hand-off (they cannot reach the lane end within one
-// sub-step).  Small register footprint -> 8 waves per SIMD; this is where most
-// vehicles are.
-template <bool SINGLE>
-__global__ __launch_bounds__(256) void k_follow(DevNet N, DevState S, DevCfg C, int n_rb, int n_lblk) {
-  int rb, lblk;
-  if (!map_block(n_rb, n_lblk, rb, lblk)) return;
-  int d = __builtin_amdgcn_readfirstlane(lblk * (int)blockDim.y + (int)threadIdx.y);
-  int r = rb * 64 + threadIdx.x;
-  if (d >= N.n_lanes || r >= S.R) return;
-  const int n = S.cnt[IDX(d)] & TSC_CNT_MASK;
-  if (n < 2) return;
-  const double interval = C.interval;
-  const double L = N.drv_length[d];
-  const double drvMax = N.drv_max_speed[d];
-  const int sb = N.drv_slot_base[d];
-  const int vbase = SINGLE ? 0 : N.set_veh_ptr[S.set[r]];
-  const double *__restrict__ g_dist = S.dist;
-  const double *__restrict__ g_speed = S.speed;
-  const int *__restrict__ g_tag = S.tag;
-  double *__restrict__ o_dist = S.ndist;
-  double *__restrict__ o_speed = S.nspeed;
-  double p_dist = g_dist[SIDX(sb)], p_speed = g_speed[SIDX(sb)];
-  int p_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(g_tag[SIDX(sb)]));
-  double c_dist = g_dist[SIDX(sb + 1)], c_speed = g_speed[SIDX(sb + 1)];
-  int c_blk = S.blk[SIDX(sb + 1)];
-  int c_tag = SINGLE ? 0 : g_tag[SIDX(sb + 1)];
-  for (int i = 1; i < n; i++) {
-    const double dist = c_dist, speed = c_speed;
-    const int blkw = c_blk, tag0 = c_tag;
-    if (i + 1 < n) { // next slot's loads before this slot's stores
-      c_dist = g_dist[SIDX(sb + i + 1)];
-      c_speed = g_speed[SIDX(sb + i + 1)];
-      c_blk = S.blk[SIDX(sb + i + 1)];
-      if (!SINGLE) c_tag = g_tag[SIDX(sb + i + 1)];
-    }
-    const int tid = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tag0));
-    const Tm t = load_tm(N, tid);
-    if ((L - dist) <= t.approach) { // k_action's
-      if (i >= TSC_HSCAN) atomicAdd(&S.errors[3], 1);
-    } else {
-      const Tm tl = load_tm(N, p_tmpl);
-      double gap = p_dist - tl.len - dist;
-      double v = t.maxSpeed;
-      v = min2(v, speed + t.maxPosAcc * interval);
-      v = min2(v, drvMax);
-      v = min2(v, car_follow_speed(speed, t, p_speed, tl, gap, interval));
       v = max2(v, speed - t.maxNegAcc * interval);
       double deltaDis;
       if (v < 0) {
@@ -627,20 +774,41 @@ __global__ __launch_bounds__(256) void k_follow(DevNet N, DevState S, DevCfg C, 
       } else {
         deltaDis = (speed + v) * interval / 2;
       }
-      if (blkw != 0) { // a blocker from its time near the previous intersection: let it expire
+      if (valid) {
+        // ---- blocker bookkeeping: slot word in place, vid-indexed entry in the other half
         int old_b = TSC_BLK_VID(blkw);
-        int new_w = (old_b >= 0) ? (1 << 30) : 0;
-        S.blk[SIDX(sb + i)] = new_w;
-        S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + i)]))] = -1;
+        int new_w = ((nblk + 1) & 0xffffff) | ((old_b >= 0) ? (1 << 30) : 0);
+        if (new_w != blkw) S.blk[SIDX(sb + it)] = new_w;
+        if (nblk >= 0 || old_b >= 0 || TSC_BLK_OLDER(blkw)) S.nbbv[IDX(vid)] = nblk;
+        // ---- move (engine: setDeltaDistance)
+        double nd = deltaDis + dist;
+        if (nd > L) {
+          nd -= L;
+          int ko = atomicAdd(&sh.ob_cnt[rl], 1);
+          if (ko < TSC_OB_MAX) {
+            sh.ob_slot[rl][ko] = it;
+            size_t ox = ((size_t)d * TSC_OB_MAX + ko) * (size_t)S.RS + (size_t)r;
+            S.obx_tag[ox] = tag;
+            S.obx_aux[ox] = aux; // lane vehicle with aux < 0: leaves the network
+            S.obx_blk[ox] = new_w;
+            S.obx_dist[ox] = nd;
+            S.obx_speed[ox] = v;
+          } else atomicAdd(&S.errors[1], 1);
+        }
+        o_dist[SIDX(sb + it)] = nd;
+        o_speed[SIDX(sb + it)] = v;
       }
-      double nd = deltaDis + dist;
-      if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
-      o_dist[SIDX(sb + i)] = nd;
-      o_speed[SIDX(sb + i)] = v;
+      __syncthreads();
     }
-    p_dist = dist;
-    p_speed = speed;
-    p_tmpl = tid;
+  }
+  __syncthreads();
+  if (own_valid) {
+    const int r = r_own;
+    int m = sh.ob_cnt[lane];
+    if (m > TSC_OB_MAX) m = TSC_OB_MAX;
+    int ob = m;
+    for (int k = 0; k < m; k++) ob |= (sh.ob_slot[lane][k] & 1023) << (2 + 10 * k);
+    S.ob[IDX(d)] = ob;
   }
 }
 
