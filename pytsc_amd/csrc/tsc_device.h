@@ -37,6 +37,7 @@ struct DevNet {
   const int *lane_out_ptr, *lane_out_links, *lane_in_ptr, *lane_in_links;
   const double *lane_len_pytsc;
   const int *lane_bins, *lane_static;
+  const int *lane_is_entry; // 1: some flow set spawns vehicles on this lane
   const int *link_start_lane, *link_end_lane, *link_type, *link_agent, *link_local;
   const uint32_t *link_avail_mask;
   const unsigned long long *link_conflict; // local-index mask of links crossing this link
@@ -68,7 +69,8 @@ struct DevState {
   int *cnt, *ob, *tail_tag, *tail_prev;
   int *obx_tag, *obx_aux, *obx_blk; // [n_drv * TSC_OB_MAX * RS] records of this sub-step's leavers
   double *obx_dist, *obx_speed;
-  double *tail_dist, *tail_speed;
+  double *tail_dist, *tail_speed;   // tail record of the committed state (the tail before a spawn)
+  double *ntail_dist, *ntail_speed; // next half: written by k_drive (quiet drivables) / k_commit, then swapped in
   // per lane [n_lanes * RS]
   int *spawn_cur, *lane_n, *lane_q;
   double *lane_sum;
@@ -79,6 +81,7 @@ struct DevState {
   double *agent_local, *agent_pressure;
   // per replica [RS]
   int *t, *set, *restarts, *fin_cnt;
+  int *nq_all; // queued vehicles on ALL lanes (Q6), accumulated by k_measure, consumed + zeroed by k_stats
   unsigned long long *fin_dsum, *fin_ssum; // sums over finished vehicles: duration, creation step
   // per vid [max_veh * RS]: committed blocker of a running vehicle, ping-pong halves
   int *bbv, *nbbv;

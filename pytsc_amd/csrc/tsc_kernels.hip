@@ -809,6 +809,12 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
     int ob = m;
     for (int k = 0; k < m; k++) ob |= (sh.ob_slot[lane][k] & 1023) << (2 + 10 * k);
     S.ob[IDX(d)] = ob;
+    // next tail record of a drivable that stays quiet (k_commit redoes it otherwise):
+    // the new position / speed of the last vehicle, written by this workgroup above
+    if (n > 0) {
+      S.ntail_dist[IDX(d)] = o_dist[SIDX(sb + n - 1)];
+      S.ntail_speed[IDX(d)] = o_speed[SIDX(sb + n - 1)];
+    }
   }
 }
 
@@ -888,7 +894,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   const int t_now = S.t[r];
   bool spawn_possible = false;
-  if (!is_link) {
+  if (!is_link && N.lane_is_entry[d]) {
     int set = S.set[r];
     int qb = N.spawn_ptr[set * N.n_lanes + d], qe = N.spawn_ptr[set * N.n_lanes + d + 1];
     if (qb != qe) {
@@ -898,14 +904,11 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   if (m_self == 0 && !arrivals && !spawn_possible) {
     // quiet drivable: only the tail record moves (and the inserted-this-step bit clears)
-    if (n > 0) {
-      S.tail_dist[IDX(d)] = q_dist[SIDX(sb + n - 1)];
-      S.tail_speed[IDX(d)] = q_speed[SIDX(sb + n - 1)];
-      if (hdr & TSC_NEW_BIT) {
-        S.tail_tag[IDX(d)] = S.tag[SIDX(sb + n - 1)];
-        S.tail_prev[IDX(d)] = -1;
-        S.cnt[IDX(d)] = n;
-      }
+    // (its next tail record was written by k_drive)
+    if (hdr & TSC_NEW_BIT) {
+      S.tail_tag[IDX(d)] = S.tag[SIDX(sb + n - 1)];
+      S.tail_prev[IDX(d)] = -1;
+      S.cnt[IDX(d)] = n;
     }
     return;
   }
@@ -939,23 +942,58 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       tl_tag = S.tag[SIDX(sb + n - 1)];
     }
   } else {
-    for (int i = 0; i < n; i++) {
-      if (i == s0 || i == s1 || i == s2) continue;
-      double nd = q_dist[SIDX(sb + i)], ns = q_speed[SIDX(sb + i)];
-      int tg = S.tag[SIDX(sb + i)];
-      if (w != i) {
-        q_dist[SIDX(sb + w)] = nd;
-        q_speed[SIDX(sb + w)] = ns;
-        S.tag[SIDX(sb + w)] = tg;
-        S.aux[SIDX(sb + w)] = S.aux[SIDX(sb + i)];
-        S.blk[SIDX(sb + w)] = S.blk[SIDX(sb + i)];
+    // leavers are (almost always) the first k vehicles of the list: then the rest shifts
+    // down by k, moved four slots per turn with all loads issued before the stores
+    const int k = m_self;
+    bool prefix = (s0 < k) && (m_self < 2 || s1 < k) && (m_self < 3 || s2 < k);
+    if (prefix) {
+      for (int i = k; i < n; i += 4) {
+        double nd[4], ns[4];
+        int tg[4], ax[4], bk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (i + u < n) {
+            nd[u] = q_dist[SIDX(sb + i + u)];
+            ns[u] = q_speed[SIDX(sb + i + u)];
+            tg[u] = S.tag[SIDX(sb + i + u)];
+            ax[u] = S.aux[SIDX(sb + i + u)];
+            bk[u] = S.blk[SIDX(sb + i + u)];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (i + u < n) {
+            q_dist[SIDX(sb + i + u - k)] = nd[u];
+            q_speed[SIDX(sb + i + u - k)] = ns[u];
+            S.tag[SIDX(sb + i + u - k)] = tg[u];
+            S.aux[SIDX(sb + i + u - k)] = ax[u];
+            S.blk[SIDX(sb + i + u - k)] = bk[u];
+            tl_dist = nd[u];
+            tl_speed = ns[u];
+            tl_tag = tg[u];
+          }
       }
-      have_tail = true;
-      tl_dist = nd;
-      tl_speed = ns;
-      tl_tag = tg;
-      old_tail_kept = (i == n - 1);
-      w++;
+      w = n - k;
+      have_tail = w > 0;
+      old_tail_kept = w > 0;
+    } else {
+      for (int i = 0; i < n; i++) {
+        if (i == s0 || i == s1 || i == s2) continue;
+        double nd = q_dist[SIDX(sb + i)], ns = q_speed[SIDX(sb + i)];
+        int tg = S.tag[SIDX(sb + i)];
+        if (w != i) {
+          q_dist[SIDX(sb + w)] = nd;
+          q_speed[SIDX(sb + w)] = ns;
+          S.tag[SIDX(sb + w)] = tg;
+          S.aux[SIDX(sb + w)] = S.aux[SIDX(sb + i)];
+          S.blk[SIDX(sb + w)] = S.blk[SIDX(sb + i)];
+        }
+        have_tail = true;
+        tl_dist = nd;
+        tl_speed = ns;
+        tl_tag = tg;
+        old_tail_kept = (i == n - 1);
+        w++;
+      }
     }
   }
   if (!have_tail) tp = -1;
@@ -1028,8 +1066,8 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   // ---- tail record (the tail BEFORE the next step's insertion)
   if (have_tail) {
-    S.tail_dist[IDX(d)] = tl_dist;
-    S.tail_speed[IDX(d)] = tl_speed;
+    S.ntail_dist[IDX(d)] = tl_dist;
+    S.ntail_speed[IDX(d)] = tl_speed;
     S.tail_tag[IDX(d)] = tl_tag;
   }
   S.tail_prev[IDX(d)] = tp;
@@ -1159,9 +1197,13 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   int q = 0;
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
+  double c_dist = n > 0 ? S.dist[SIDX(sb)] : 0.0, c_speed = n > 0 ? S.speed[SIDX(sb)] : 0.0;
   for (int i = 0; i < n; i++) {
-    double dist = S.dist[SIDX(sb + i)];
-    double speed = S.speed[SIDX(sb + i)];
+    const double dist = c_dist, speed = c_speed;
+    if (i + 1 < n) { // next slot in flight while this one is binned
+      c_dist = S.dist[SIDX(sb + i + 1)];
+      c_speed = S.speed[SIDX(sb + i + 1)];
+    }
     if (speed < 0.1) q++;
     sum += speed;
     if (bins > 0) {
@@ -1197,6 +1239,7 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   }
   S.lane_n[IDX(l)] = n;
   S.lane_q[IDX(l)] = q;
+  if (q) atomicAdd(&S.nq_all[r], q);
   S.lane_sum[IDX(l)] = sum;
   S.lane_in_bits[IDX(l)] = ib;
   S.lane_out_bits[IDX(l)] = obits;
@@ -1439,9 +1482,11 @@ __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.R) return;
   const int A = N.n_agents;
-  long long nq_all = 0, nveh_all = 0;
+  long long nq_all = S.nq_all[r], nveh_all = 0;
+  S.nq_all[r] = 0;
   double dens = 0, nms = 0, tvs = 0;
-  for (int l = 0; l < N.n_lanes; l++) {
+  if (out.stats_dev) nq_all = 0;
+  for (int l = 0; out.stats_dev && l < N.n_lanes; l++) {
     int n = S.lane_n[IDX(l)];
     nq_all += S.lane_q[IDX(l)];
     nveh_all += n;
