@@ -133,30 +133,54 @@ static inline int grid_for(int n_rb, int n_rowblk) { return ((n_rb + 7) / 8) * 8
 // their start lane heading for them.  Restates the candidate set of the engine's
 // notifyCross as three 64-bit masks; the exact
 // per-cross foe is resolved lazily by find_foe() only for occupied links.
-__global__ __launch_bounds__(256) void k_notify(DevNet N, DevState S, int n_rb, int n_ablk) {
-  int rb, ablk;
-  if (!map_block(n_rb, n_ablk, rb, ablk)) return;
-  int a = __builtin_amdgcn_readfirstlane(ablk * (int)blockDim.y + (int)threadIdx.y);
-  int r = rb * 64 + threadIdx.x;
-  if (a >= N.n_agents || r >= S.R) return;
-  if (a == 0) S.t[r] += 1; // the step index being executed from here on
-  unsigned long long oe = 0, ov = 0, os = 0;
-  int lb = N.agent_link_ptr[a], le = N.agent_link_ptr[a + 1];
-  for (int li = lb; li < le; li++) {
-    int link = N.agent_links[li];
-    int k = link - N.n_lanes;
-    unsigned long long bit = 1ull << (li - lb);
-    if ((S.cnt[IDX(link)] & TSC_CNT_MASK) > 0) ov |= bit;
-    int e = N.link_end_lane[k];
-    int he = S.cnt[IDX(e)];
-    if ((he & TSC_CNT_MASK) > 0 && !(he & TSC_NEW_BIT) && S.tail_prev[IDX(e)] == link) oe |= bit;
-    int sl = N.link_start_lane[k];
-    int hs = S.cnt[IDX(sl)];
-    if ((hs & TSC_CNT_MASK) > 0 && S.aux[SIDX(N.drv_slot_base[sl])] == link) os |= bit;
+#define NOTIFY_WAVES 12
+// One workgroup = one intersection x 64 replicas: its waves split the intersection's
+// lane-links, each lane-link's three candidate bits are OR-ed in LDS, wave 0 writes
+// the masks (coalesced).
+__global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState S, int n_rb, int n_agents) {
+  __shared__ unsigned long long m_e[64], m_v[64], m_s[64];
+  int rb, a;
+  const bool live = map_block(n_rb, n_agents, rb, a);
+  a = __builtin_amdgcn_readfirstlane(a);
+  const int lx = threadIdx.x, wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const int r = rb * 64 + lx;
+  const bool mine = live && r < S.R;
+  if (wy == 0) {
+    m_e[lx] = 0;
+    m_v[lx] = 0;
+    m_s[lx] = 0;
+    if (mine && a == 0) S.t[r] += 1; // the step index being executed from here on
   }
-  S.occ_e[IDX(a)] = oe;
-  S.occ_v[IDX(a)] = ov;
-  S.occ_s[IDX(a)] = os;
+  __syncthreads();
+  if (mine) {
+    unsigned long long oe = 0, ov = 0, os = 0;
+    const int lb = N.agent_link_ptr[a], le = N.agent_link_ptr[a + 1];
+    for (int li = lb + wy; li < le; li += NOTIFY_WAVES) {
+      const int link = N.agent_links[li];
+      const int k = link - N.n_lanes;
+      const unsigned long long bit = 1ull << (li - lb);
+      const int e = N.link_end_lane[k];
+      const int sl = N.link_start_lane[k];
+      // independent loads, issued together
+      const int cl = S.cnt[IDX(link)];
+      const int he = S.cnt[IDX(e)];
+      const int tpv = S.tail_prev[IDX(e)];
+      const int hs = S.cnt[IDX(sl)];
+      const int ax = S.aux[SIDX(N.drv_slot_base[sl])];
+      if ((cl & TSC_CNT_MASK) > 0) ov |= bit;
+      if ((he & TSC_CNT_MASK) > 0 && !(he & TSC_NEW_BIT) && tpv == link) oe |= bit;
+      if ((hs & TSC_CNT_MASK) > 0 && ax == link) os |= bit;
+    }
+    if (oe) atomicOr(&m_e[lx], oe);
+    if (ov) atomicOr(&m_v[lx], ov);
+    if (os) atomicOr(&m_s[lx], os);
+  }
+  __syncthreads();
+  if (mine && wy == 0) {
+    S.occ_e[IDX(a)] = m_e[lx];
+    S.occ_v[IDX(a)] = m_v[lx];
+    S.occ_s[IDX(a)] = m_s[lx];
+  }
 }
 
 // ------------------------------------------------------------------ find_foe
