@@ -892,11 +892,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   // the half k_action just wrote: it becomes the committed state after this kernel
   double *__restrict__ q_dist = S.ndist;
   double *__restrict__ q_speed = S.nspeed;
-  int hdr = S.cnt[IDX(d)];
-  int n = hdr & TSC_CNT_MASK;
-  const int o_self = n > 0 ? S.ob[IDX(d)] : 0;
-  const int m_self = o_self & 3;
-  // ---- is anything arriving?
+  // ---- everything the quiet test needs is loaded up front, in one round trip
   int fb, fe;
   if (is_link) {
     fb = 0;
@@ -905,17 +901,51 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     fb = N.lane_in_ptr[d];
     fe = N.lane_in_ptr[d + 1];
   }
-  bool arrivals = false;
-  for (int q = fb; q < fe; q++) {
-    int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
-    int o = S.ob[IDX(f)];
-    int m = o & 3;
+  const int hdr = S.cnt[IDX(d)];
+  const int o_raw = S.ob[IDX(d)];
+  int o_feed[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (fb + q < fe) {
+      const int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[fb + q];
+      o_feed[q] = S.ob[IDX(f)];
+    }
+  const int n = hdr & TSC_CNT_MASK;
+  const int o_self = n > 0 ? o_raw : 0;
+  const int m_self = o_self & 3;
+  // ---- is anything arriving?
+  int n_arr = 0, first_f = -1; // arrivals, and the outbox (drivable, index) of the first one found
+  int first_k = 0;
+  if (is_link) {
+    const int f = N.link_start_lane[d - N.n_lanes];
+    const int m = o_feed[0] & 3;
     for (int k = 0; k < m; k++) {
       size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
-      int ax = S.obx_aux[ox];
-      if (is_link ? (ax == d) : true) arrivals = true;
+      if (S.obx_aux[ox] == d) {
+        if (n_arr == 0) {
+          first_f = f;
+          first_k = k;
+        }
+        n_arr++;
+      }
+    }
+  } else {
+    // every vehicle leaving a feeder lane-link comes here
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (fb + q < fe && (o_feed[q] & 3)) {
+        if (n_arr == 0) first_f = N.lane_in_links[fb + q];
+        n_arr += o_feed[q] & 3;
+      }
+    for (int q = fb + 4; q < fe; q++) {
+      int m = S.ob[IDX(N.lane_in_links[q])] & 3;
+      if (m) {
+        if (n_arr == 0) first_f = N.lane_in_links[q];
+        n_arr += m;
+      }
     }
   }
+  const bool arrivals = n_arr > 0;
   const int t_now = S.t[r];
   bool spawn_possible = false;
   if (!is_link && N.lane_is_entry[d]) {
@@ -1036,6 +1066,14 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       double best_nd = -1e300;
       int best_vid = 0x7fffffff, best_f = -1;
       size_t best_ox = 0;
+      if (n_arr == 1) {
+        // the usual case, one arrival: no ordering needed
+        if (pass > 0) break;
+        best_f = first_f;
+        best_ox = ((size_t)first_f * TSC_OB_MAX + first_k) * (size_t)S.RS + (size_t)r;
+        best_nd = S.obx_dist[best_ox];
+        best_vid = TSC_TAG_VID(S.obx_tag[best_ox]);
+      } else
       for (int q = fb; q < fe; q++) {
         int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
         int o = S.ob[IDX(f)];
