@@ -378,14 +378,15 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 // the same few 512-byte rows.  The execution stage issues its loads in groups
 // (item + leader slot; headers of the out-links and of the own end lane) so that a
 // batch costs a few memory round trips instead of one per dependent lookup.
-#define TSC_QCAP 256
+#define TSC_QCAP 512
 #define TSC_QMASK (TSC_QCAP - 1)
+#define TSC_EU 2 /* slots enumerated per turn: a queue grows by at most 64 * TSC_EU (< TSC_QCAP - 64) */
 #define TSC_MAXQ 4 /* out-links of a lane (checked at create): one H queue per out-link */
 #define TSC_NQ (TSC_MAXQ + 1)
 #define TSC_QF TSC_MAXQ /* queue of plain followers */
 
 struct DriveShared {
-  int meta[TSC_NQ][TSC_QCAP]; // (replica within block << 16) | slot
+  unsigned short meta[TSC_NQ][TSC_QCAP]; // (replica within block << 10) | slot
   unsigned long long oe[64], ov[64], osg[64];
   int raw[64], vbase[64], ob_cnt[64], ob_slot[64][TSC_OB_MAX];
 };
@@ -460,11 +461,19 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
   int p_tmpl = 0;
   int i = 0;
   bool more = true;
-  // software pipeline of the enumeration: two slots per turn, the next two in flight
-  double c_dist[2] = {0, 0}, c_speed[2] = {0, 0};
-  int c_blk[2] = {0, 0}, c_tag[2] = {0, 0}, c_aux[2] = {-1, -1};
+  // software pipeline of the enumeration: TSC_EU slots per turn, the next TSC_EU in flight
+  double c_dist[TSC_EU], c_speed[TSC_EU];
+  int c_blk[TSC_EU], c_tag[TSC_EU], c_aux[TSC_EU];
 #pragma unroll
-  for (int u = 0; u < 2; u++)
+  for (int u = 0; u < TSC_EU; u++) {
+    c_dist[u] = 0;
+    c_speed[u] = 0;
+    c_blk[u] = 0;
+    c_tag[u] = 0;
+    c_aux[u] = -1;
+  }
+#pragma unroll
+  for (int u = 0; u < TSC_EU; u++)
     if (u < n) {
       const int r = r_own;
       c_dist[u] = g_dist[SIDX(sb + u)];
@@ -485,11 +494,11 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
       if (pick < 0) break;
     }
     if (pick < 0) {
-      // ------------------------------------------------ (1) enumerate slots i, i+1
-      double dist2[2], speed2[2];
-      int blk2[2], tag2[2], aux2[2];
+      // ------------------------------------------------ (1) enumerate slots i .. i+TSC_EU-1
+      double dist2[TSC_EU], speed2[TSC_EU];
+      int blk2[TSC_EU], tag2[TSC_EU], aux2[TSC_EU];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < TSC_EU; u++) {
         dist2[u] = c_dist[u];
         speed2[u] = c_speed[u];
         blk2[u] = c_blk[u];
@@ -497,17 +506,17 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         aux2[u] = c_aux[u];
       }
 #pragma unroll
-      for (int u = 0; u < 2; u++)
-        if (i + 2 + u < n) {
+      for (int u = 0; u < TSC_EU; u++)
+        if (i + TSC_EU + u < n) {
           const int r = r_own;
-          c_dist[u] = g_dist[SIDX(sb + i + 2 + u)];
-          c_speed[u] = g_speed[SIDX(sb + i + 2 + u)];
-          c_blk[u] = S.blk[SIDX(sb + i + 2 + u)];
-          if (!IS_LINK) c_aux[u] = g_aux[SIDX(sb + i + 2 + u)];
-          if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + 2 + u)];
+          c_dist[u] = g_dist[SIDX(sb + i + TSC_EU + u)];
+          c_speed[u] = g_speed[SIDX(sb + i + TSC_EU + u)];
+          c_blk[u] = S.blk[SIDX(sb + i + TSC_EU + u)];
+          if (!IS_LINK) c_aux[u] = g_aux[SIDX(sb + i + TSC_EU + u)];
+          if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + TSC_EU + u)];
         }
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < TSC_EU; u++) {
         const int is = i + u;
         const bool active = is < n;
         const double dist = dist2[u], speed = speed2[u];
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
           if (m) {
             const int rank =
                 __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (put) sh.meta[q][(head[q] + count[q] + rank) & TSC_QMASK] = (lane << 16) | is;
+            if (put) sh.meta[q][(head[q] + count[q] + rank) & TSC_QMASK] = (unsigned short)((lane << 10) | is);
             count[q] += __builtin_popcountll(m);
           }
         }
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         p_speed = speed;
         p_tmpl = tid;
       }
-      i += 2;
+      i += TSC_EU;
       more = __builtin_amdgcn_ballot_w64(i < n) != 0;
       continue;
     }
@@ -584,8 +593,8 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         count[q] -= nb;
       }
     const bool valid = lane < nb;
-    const int rl = valid ? (meta >> 16) : lane; // replica of the item within this block
-    const int it = valid ? (meta & 0xffff) : 0;
+    const int rl = valid ? (meta >> 10) : lane; // replica of the item within this block
+    const int it = valid ? (meta & 1023) : 0;
     const int r = rb * 64 + rl;
     const int vbase = sh.vbase[rl];
     if (pick == TSC_QF) {
@@ -634,9 +643,16 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
       const int el = IS_LINK ? end_lane : (link >= 0 ? N.link_end_lane[lk] : 0);
       const int raw = sh.raw[rl];
       const unsigned long long oe = sh.oe[rl], ov = sh.ov[rl], os_green = sh.osg[rl];
-      // ---- load group 0: the item and its list predecessor
+      // ---- ONE load group: the item and its list predecessor, the header of the own
+      //      link's end lane (look-ahead, canEnter) and, for head vehicles, the tails of all
+      //      out-links (look-ahead).  Addresses depend only on (replica, slot) and
+      //      wave-uniform table entries, so everything is in flight together.
       double dist = 0, speed = 0, pd = 0, ps = 0;
       int tag = 0, aux = -1, blkw = 0, ptag = 0;
+      int l_cnt[TSC_MAXQ], l_tt[TSC_MAXQ];
+      double l_td[TSC_MAXQ], l_ts[TSC_MAXQ];
+      int e_hdr = 0, e_tt = 0;
+      double e_td = 0, e_ts = 0;
       if (valid) {
         dist = g_dist[SIDX(sb + it)];
         speed = g_speed[SIDX(sb + it)];
@@ -649,14 +665,7 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
           if (!SINGLE) ptag = g_tag[SIDX(sb + it - 1)];
         }
       }
-      // ---- load group 1: headers of the out-links (tails: look-ahead of a head vehicle)
-      //      and of the own link's end lane (look-ahead, canEnter) -- all independent
-      int l_cnt[TSC_MAXQ], l_tt[TSC_MAXQ];
-      double l_td[TSC_MAXQ], l_ts[TSC_MAXQ];
-      int e_hdr = 0, e_tt = 0;
-      double e_td = 0, e_ts = 0;
-      const bool has_link = IS_LINK ? false : (valid && aux >= 0); // then aux == link (bucketed)
-      if (IS_LINK ? (valid && it == 0) : has_link) {
+      if (valid && (IS_LINK ? it == 0 : link >= 0)) {
         e_hdr = S.cnt[IDX(el)];
         e_td = S.tail_dist[IDX(el)];
         e_ts = S.tail_speed[IDX(el)];
@@ -669,15 +678,15 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
           l_tt[qq] = 0;
           l_td[qq] = 0;
           l_ts[qq] = 0;
-          if (qb + qq < qe && has_link && it == 0) {
-            const int ll = N.lane_out_links[qb + qq];
-            l_cnt[qq] = S.cnt[IDX(ll)] & TSC_CNT_MASK;
-            l_td[qq] = S.tail_dist[IDX(ll)];
-            l_ts[qq] = S.tail_speed[IDX(ll)];
-            if (!SINGLE) l_tt[qq] = S.tail_tag[IDX(ll)];
+          if (olk[qq] >= 0 && valid && it == 0) {
+            l_cnt[qq] = S.cnt[IDX(olk[qq])] & TSC_CNT_MASK;
+            l_td[qq] = S.tail_dist[IDX(olk[qq])];
+            l_ts[qq] = S.tail_speed[IDX(olk[qq])];
+            if (!SINGLE) l_tt[qq] = S.tail_tag[IDX(olk[qq])];
           }
         }
       }
+      const bool has_link = IS_LINK ? false : (valid && aux >= 0); // then aux == link (bucketed)
       const double my_len = link >= 0 ? N.drv_length[link] : 0.0;
       const int vid = TSC_TAG_VID(tag);
       const int tid = tmpl_of<SINGLE>(N, vbase, vid);

@@ -18,6 +18,6 @@ print("vehicles/replica", eng.mean_vehicles())
 eng.lib.tsc_debug_time_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 ms = C.c_double()
 for which, name in ((8, "notify"), (1, "lanes"), (2, "links"), (32, "commit(after)")):
-    for ab in ((0, 128, 64, 16, 1, 256) if which in (1, 2) else (0,)):
+    for ab in ((0, 256, 8 << 16, 16 << 16, 32 << 16, (32 << 16) | 256) if which == 1 else (0,)):
         eng.lib.tsc_debug_time_action(eng.h, ab, which, 5, C.byref(ms))
         print(name, "ablate", ab, "us", round(ms.value * 1e3, 1))
