@@ -12,7 +12,7 @@ replicas per GPU); torch.distributed is used only for the barrier around the
 timed region and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line (rank 0) with the throughput, the roofline object of the
-dominant kernel (k_action, timed live with HIP events on its stream) and the CPU
+dominant kernel (k_drive, timed live with HIP events on its stream) and the CPU
 baseline (the scalar oracle on one host core, bounded sample).
 """
 import argparse
@@ -152,7 +152,7 @@ def main():
 
     if rank == 0:
         # roofline of the dominant kernel: algorithmic bytes per
-        # agent-env-step B = 48*V_a + 1356; one k_action launch
+        # agent-env-step B = 48*V_a + 1356; one k_drive launch
         # advances R*A agents by one of the delta_time sub-steps = R*A/5 units.
         va = 0.5 * (v0 + v1) / A
         bytes_per_unit = 48.0 * va + 1356.0
@@ -175,7 +175,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                "kernel": "k_action", "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
+                "kernel": "k_drive (lane grid; the lane-link grid runs beside it on a side stream)",
+                "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
                 "bytes_per_agent_env_step": bytes_per_unit, "V_a": va,
                 "note": "latency/occupancy-bound f64 scalar work, not HBM-bound (DESIGN.md §5)",
             },
