@@ -245,6 +245,28 @@ def random_walk_route(rn, conn, out_set, start_road, rng, turn_probs, max_len):
             return route
 
 
+def _graph_diameter(rn):
+    """Diameter of the directed intersection graph (longest shortest path), BFS."""
+    adj = {}
+    for road in rn.roads:
+        adj.setdefault(road["startIntersection"], set()).add(road["endIntersection"])
+        adj.setdefault(road["endIntersection"], set())
+    best = 0
+    for src in adj:
+        dist = {src: 0}
+        frontier = [src]
+        while frontier:
+            nxt = []
+            for u in frontier:
+                for v in adj[u]:
+                    if v not in dist:
+                        dist[v] = dist[u] + 1
+                        nxt.append(v)
+            frontier = nxt
+        best = max(best, max(dist.values()))
+    return best
+
+
 def poisson_flows(rn, rate_veh_per_hour=700.0, horizon=3600, seed=0,
                   turn_probs=(0.1, 0.3, 0.6), vehicle=None, max_len=None):
     """Poisson demand: exponential inter-arrival times (mean 3600/rate s) on
@@ -255,7 +277,7 @@ def poisson_flows(rn, rate_veh_per_hour=700.0, horizon=3600, seed=0,
     conn = _road_turns(rn)
     out_set = set(out)
     if max_len is None:
-        max_len = rn.n_agents + 2
+        max_len = _graph_diameter(rn) + 2  # as trip_generator.py:95-108 (nx.diameter(G) + 2)
     mean = 3600.0 / rate_veh_per_hour
     flows = []
     for road in inc:

@@ -1,0 +1,107 @@
+"""GPU: the other BASELINE configs at reduced replica counts against the oracle
+(16x16 grid = occupancy stress, multi flow sets with sequential restarts), and
+size-independent properties at the full replica count."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(scen, R, **hip):
+    from pytsc_amd.config import Config
+    from pytsc_amd.scenario import build_tables
+
+    cfg = Config(scen, signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
+    return build_tables(cfg, n_replicas=R)
+
+
+def test_16x16_grid_matches_oracle(oracle_lib):
+    """BASELINE config 2 shape (16x16, 256 agents) at R = 2, 40 env steps."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(flow_rate=700.0, n_flow_sets=1, sim_length=600)
+    eng = VecEngine(_tables("syn_16x16", 2, **kw))
+    orc = oracle_lib.Oracle(_tables("syn_16x16", 1, **kw))
+    rng = np.random.default_rng(3)
+    out = orc.observe()
+    for s in range(40):
+        m = out.mask[0]
+        acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        out = orc.step(acts[None])
+        buf = eng.step(torch.tensor(np.repeat(acts[None], 2, 0), dtype=torch.int32, device="cuda"))
+        for r in (0, 1):
+            assert np.array_equal(buf["obs"][r].cpu().numpy(), out.obs[0]), s
+            assert np.array_equal(buf["stats"][r].cpu().numpy(), out.stats[0]), s
+            assert np.array_equal(buf["local_reward64"][r].cpu().numpy(), out.local_reward64[0]), s
+    a, b = orc.snapshot(0), eng.snapshot(1)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert eng.errors() == 0
+    eng.close()
+
+
+def test_flow_sets_and_sequential_restart_match_oracle(oracle_lib):
+    """3 flow sets, sequential advance on restart (backends/cityflow/config.py:63-76),
+    short simulated 'hour' so that restarts happen inside the test."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(flow_rate=800.0, n_flow_sets=3, sim_length=100, episode_limit=50,
+              flow_rate_type="sequential")
+    R = 5
+    eng = VecEngine(_tables("syn_2x2", R, **kw))
+    orc = oracle_lib.Oracle(_tables("syn_2x2", R, **kw))
+    rng = np.random.default_rng(4)
+    out = orc.observe()
+    for s in range(70):
+        m = out.mask
+        acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        out = orc.step(acts)
+        buf = eng.step(torch.tensor(acts, device="cuda"))
+        assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+        assert np.array_equal(buf["stats"].cpu().numpy(), out.stats), s
+        assert np.array_equal(buf["terminated"].cpu().numpy(), out.terminated), s
+        if out.terminated.any():
+            assert (s + 1) % 20 == 0
+            mask = out.terminated.copy()
+            if s < 20:
+                assert mask.all()
+                mask[1] = 0  # leave one replica running past its simulated hour
+            orc.reset(mask)
+            eng.reset(torch.tensor(mask, device="cuda"))
+            out = orc.observe()
+            buf = eng.observe()
+            assert np.array_equal(buf["obs"].cpu().numpy(), out.obs)
+    assert eng.errors() == 0 and orc.errors() == 0
+    eng.close()
+
+
+def test_full_size_properties_4x4_r4096():
+    """BASELINE config 1 size: replicas sharing a flow set stay bit-identical under
+    identical actions (K6), vehicles are conserved (K5), no device error."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    R = 4096
+    eng = VecEngine(_tables("syn_4x4", R, flow_rate=700.0, n_flow_sets=4),
+                    want=("obs", "mask", "stats", "global_reward"))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    buf = eng.observe()
+    for s in range(60):
+        u = torch.rand((4, 16, 16), device="cuda", generator=g).clamp_min(1e-6)
+        # the same action for every replica of a flow set
+        acts = (u.repeat(R // 4, 1, 1) * buf["mask"]).argmax(-1).to(torch.int32)
+        buf = eng.step(acts)
+    obs = buf["obs"]
+    for k in range(4):
+        assert torch.equal(obs[k::4], obs[k].expand_as(obs[k::4]))
+        assert torch.equal(buf["stats"][k::4], buf["stats"][k].expand_as(buf["stats"][k::4]))
+    assert not torch.equal(obs[0], obs[1])
+    mean_veh = eng.mean_vehicles()
+    assert 100 < mean_veh < 3000
+    assert eng.errors() == 0
+    eng.close()
