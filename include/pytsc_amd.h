@@ -259,6 +259,14 @@ int tsc_lane_detail(tsc_handle_t h, int32_t *lane_counts_dev,
                     double *lane_speed_dev, double *posmat_dev,
                     int32_t max_bins, void *stream);
 
+/* Per-lane counts over the visibility windows of the last measure pass, for the
+ * rule-based controllers (reference controllers/controllers.py:93-242 read
+ * position_matrix[-visibility:] of incoming and [:visibility] of outgoing lanes):
+ *  window_counts_dev [R, n_lanes, 3] int32 =
+ *    (# bins == 0.0 in the incoming window, # bins >= 0 in the incoming window,
+ *     # bins >= 0 in the outgoing window). */
+int tsc_lane_window_counts(tsc_handle_t h, int32_t *window_counts_dev, void *stream);
+
 /* Synchronous dump of one replica's vehicles to HOST arrays (capacity `cap`):
  * drivable index, distance, speed, vid.  Returns the vehicle count (>= 0) or a
  * negative error.  Vehicles inserted for the *next* sub-step are excluded. */

@@ -37,6 +37,7 @@ def load():
     lib.tsco_lane_detail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.tsco_snapshot.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
+    lib.tsco_lane_window_counts.argtypes = [C.c_void_p, C.c_void_p]
     lib.tsco_n_actions.argtypes = [C.c_void_p]
     lib.tsco_max_bins.argtypes = [C.c_void_p]
     lib.tsco_engine_next_step.argtypes = [C.c_void_p, C.c_int]
@@ -127,6 +128,11 @@ class Oracle:
         self.lib.tsco_lane_detail(self.h, counts.ctypes.data, speed.ctypes.data,
                                   pm.ctypes.data if with_posmat else None, self.max_bins)
         return counts, speed, pm
+
+    def lane_window_counts(self):
+        out = np.zeros((self.tables.n_replicas, self.tables.n_lanes, 3), np.int32)
+        self.lib.tsco_lane_window_counts(self.h, out.ctypes.data)
+        return out
 
     def snapshot(self, rep=0, cap=65536):
         drv = np.zeros(cap, np.int32)

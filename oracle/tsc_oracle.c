@@ -1126,6 +1126,29 @@ int tsco_lane_detail(void *h, int32_t *lane_counts, double *lane_speed, double *
   return 0;
 }
 
+/* controllers' window counts (controllers/controllers.py:93-242) from the full matrices */
+int tsco_lane_window_counts(void *h, int32_t *out) {
+  orc_t *o = (orc_t *)h;
+  int nl = o->net.n_lanes, vis = o->cfg.visibility;
+  for (int i = 0; i < o->cfg.n_replicas; i++) {
+    rep_t *r = &o->rep[i];
+    for (int l = 0; l < nl; l++) {
+      int plen = posmat_len(o, r, l), nz = 0, no = 0, nout = 0;
+      for (int b = plen - vis; b < plen; b++) {
+        double v = posmat_at(o, r, l, b);
+        nz += v == 0.0;
+        no += v >= 0.0;
+      }
+      for (int b = 0; b < vis; b++) nout += posmat_at(o, r, l, b) >= 0.0;
+      int32_t *p = out + ((size_t)i * nl + l) * 3;
+      p[0] = nz;
+      p[1] = no;
+      p[2] = nout;
+    }
+  }
+  return 0;
+}
+
 int tsco_snapshot(void *h, int32_t rep, int32_t cap, int32_t *drv, double *dist, double *speed, int32_t *vid) {
   orc_t *o = (orc_t *)h;
   rep_t *r = &o->rep[rep];

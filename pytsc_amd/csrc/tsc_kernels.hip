@@ -1356,6 +1356,25 @@ __global__ void k_lane_detail(DevNet N, DevState S, int *lane_counts, double *la
   lane_speed[(size_t)r * N.n_lanes + l] = S.lane_sum[IDX(l)];
 }
 
+__global__ void k_lane_window_counts(DevNet N, DevState S, DevCfg C, int *out, int n_rb, int n_lblk) {
+  int rb, lblk;
+  if (!map_block(n_rb, n_lblk, rb, lblk)) return;
+  int l = lblk * (int)blockDim.y + (int)threadIdx.y;
+  int r = rb * 64 + threadIdx.x;
+  if (l >= N.n_lanes || r >= S.R) return;
+  unsigned int ib = S.lane_in_bits[IDX(l)], ob = S.lane_out_bits[IDX(l)];
+  int nz = 0, no = 0;
+  for (int b = 0; b < C.visibility; b++) {
+    unsigned int t3 = (ib >> (3 * b)) & 7u;
+    nz += (t3 >> 1) & 1u;
+    no += t3 & 1u;
+  }
+  int *o = out + ((size_t)r * N.n_lanes + l) * 3;
+  o[0] = nz;
+  o[1] = no;
+  o[2] = __builtin_popcount(ob);
+}
+
 // ------------------------------------------------------------------ k_agent
 __device__ __forceinline__ double lane_mean_speed(const DevState &S, int r, int l) {
   int n = S.lane_n[IDX(l)];

@@ -106,6 +106,13 @@ class VecEngine:
                                             self._stream()), "tsc_lane_detail")
         return counts, speed, pm
 
+    def lane_window_counts(self):
+        """[R, n_lanes, 3] int32: (# == 0.0, # >= 0 in the incoming window, # >= 0 in the outgoing window)."""
+        out = torch.zeros((self.R, self.tables.n_lanes, 3), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.tsc_lane_window_counts(self.h, C.c_void_p(out.data_ptr()), self._stream()),
+                   "tsc_lane_window_counts")
+        return out
+
     def snapshot(self, rep=0, cap=65536):
         drv = np.zeros(cap, np.int32)
         dist = np.zeros(cap, np.float64)

@@ -34,6 +34,9 @@ class OracleEngine:
         c, s, p = self.o.lane_detail(with_posmat)
         return torch.from_numpy(c), torch.from_numpy(s), (torch.from_numpy(p) if p is not None else None)
 
+    def lane_window_counts(self):
+        return torch.from_numpy(self.o.lane_window_counts())
+
     def snapshot(self, rep=0, cap=65536):
         return self.o.snapshot(rep, cap)
 

@@ -55,3 +55,22 @@ def test_vec_env_batched_api_and_partial_restart():
     assert torch.equal(buf["obs"][1], buf["obs"][3])
     assert env.engine.errors() == 0
     env.close()
+
+
+def test_vec_smac_wrapper():
+    import torch
+
+    from pytsc_amd.wrappers.vec import VecEPyMARLTrafficSignalNetwork
+
+    env = VecEPyMARLTrafficSignalNetwork("syn_2x2", n_replicas=64, signal={"action_space": "phase_selection",
+                                                                           "round_robin": False})
+    info = env.get_env_info()
+    assert info["n_agents"] == 4 and info["n_actions"] == 16 and info["obs_shape"] == 324
+    obs, state = env.reset()
+    assert obs.shape == (64, 4, 324) and state.shape == (64, 4, 212)
+    a = env.tsc_env.random_valid_actions()
+    obs, reward, done, truncated, step_info = env.step(a)
+    assert reward.shape == (64,) and done.shape == (64,) and truncated is False
+    assert torch.allclose(reward * 4, env.tsc_env.get_reward())
+    assert set(step_info) >= {"time_step", "n_queued", "episode_limit"}
+    env.close()
