@@ -67,7 +67,8 @@ struct DevState {
   int *tag, *aux, *blk;   // blk: blocker word (TSC_BLK_*), updated in place
   // per drivable [n_drv * RS]
   int *cnt, *ob, *tail_tag, *tail_prev;
-  int *obx_tag, *obx_aux, *obx_blk; // [n_drv * TSC_OB_MAX * RS] records of this sub-step's leavers
+  // outbox of this sub-step's leavers: ob = how many (appended with atomics), records [n_drv * TSC_OB_MAX * RS]
+  int *obx_slot, *obx_tag, *obx_aux, *obx_blk;
   double *obx_dist, *obx_speed;
   double *tail_dist, *tail_speed;   // tail record of the committed state (the tail before a spawn)
   double *ntail_dist, *ntail_speed; // next half: written by k_drive (quiet drivables) / k_commit, then swapped in
@@ -85,6 +86,9 @@ struct DevState {
   unsigned long long *fin_dsum, *fin_ssum; // sums over finished vehicles: duration, creation step
   // per vid [max_veh * RS]: committed blocker of a running vehicle, ping-pong halves
   int *bbv, *nbbv;
+  // work lists of k_enum for k_heavy: [(lane * n_rb + rb) * TSC_MAXQ + q] counts, * TSC_HCAP items
+  int *hq_cnt;
+  unsigned short *hq_items;
   int *errors; // [4]: slot overflow, outbox overflow, bad action, other
 };
 

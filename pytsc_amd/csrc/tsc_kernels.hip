@@ -359,247 +359,82 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 }
 
 // ------------------------------------------------------------------ k_drive
-// One workgroup = ONE wavefront = 64 replicas of ONE drivable, in two roles:
-//  (1) enumeration: lane l walks the slots of ITS replica (coalesced loads along
-//      the replica axis, wave-uniform topology) and classifies every vehicle:
-//        - plain follower that is stopped in a stopped queue  -> result is known
-//          without arithmetic (v = 0, position unchanged), stored at once;
+// The engine sub-step's decision stage, three kernels with the same two roles:
+//  (1) enumeration: one wavefront = 64 replicas of ONE drivable; lane l walks the
+//      slots of ITS replica (coalesced loads along the replica axis, wave-uniform
+//      topology, software-pipelined) and classifies every vehicle:
+//        - lane vehicle stopped in a stopped queue -> result known without
+//          arithmetic (v = 0, position unchanged), stored at once;
 //        - plain follower (not the head, not within the approach distance of the
-//          lane end)                                            -> queue F in LDS;
-//        - head / near the lane end / on a lane-link           -> queue H in LDS;
-//  (2) execution: whenever a queue holds 64 work items, the 64 lanes each take one
-//      item (whatever replica and slot it came from) and run the car-following /
-//      intersection logic with all lanes busy.
+//          lane end)                                  -> work queue F;
+//        - head / near the lane end / on a lane-link -> work queue H of its next
+//          lane-link;
+//  (2) execution: 64 work items at a time, one per lane -- whatever replica and slot
+//      they came from -- run the car-following / intersection logic with all lanes
+//      busy and the loads of a batch issued as one group.
 // Replicas hold very different numbers of vehicles, so walking slots in lock-step
-// leaves most lanes idle (23 % of VALU lanes active in the v1 kernel); the
-// engine's update is Jacobi (every decision reads only committed state), so
-// vehicles can be executed in any grouping.  Items of a batch come from
-// neighbouring replicas of the same drivable: their global accesses stay within
-// the same few 512-byte rows.  The execution stage issues its loads in groups
-// (item + leader slot; headers of the out-links and of the own end lane) so that a
-// batch costs a few memory round trips instead of one per dependent lookup.
+// leaves most lanes idle (23 % of VALU lanes active in the v1 kernel); the engine's
+// update is Jacobi (every decision reads only committed state), so vehicles can be
+// executed in any grouping.  Items of a batch come from neighbouring replicas of
+// the same drivable: their global accesses stay within the same few 512-byte rows.
+//   k_enum   (lanes): enumeration + follower batches; H queues go to global lists.
+//                     Small register footprint -> 8 waves per SIMD.
+//   k_heavy  (lanes): one wavefront per (lane, 64 replicas, out-link) executes that list.
+//   k_drive_link    : enumeration + execution for lane-links (few vehicles each), run
+//                     on a side stream beside k_heavy.
 #define TSC_QCAP 512
 #define TSC_QMASK (TSC_QCAP - 1)
-#define TSC_EU 2 /* slots enumerated per turn: a queue grows by at most 64 * TSC_EU (< TSC_QCAP - 64) */
-#define TSC_MAXQ 4 /* out-links of a lane (checked at create): one H queue per out-link */
-#define TSC_NQ (TSC_MAXQ + 1)
-#define TSC_QF TSC_MAXQ /* queue of plain followers */
+#define TSC_EU 4    /* slots enumerated per turn in k_enum */
+#define TSC_MAXQ 4  /* out-links of a lane (checked at create): one H list per out-link */
+#define TSC_HCAP 512 /* items per global work list */
+#define TSC_NLIST (TSC_MAXQ + 1) /* work lists per (lane, replica block): one per out-link + plain followers */
+#define TSC_ITEM(lane, slot, tail) ((unsigned short)(((tail) ? 0x8000 : 0) | ((lane) << 9) | (slot)))
+#define TSC_ITEM_TAIL(m) (((m) >> 15) & 1)
+#define TSC_ITEM_LANE(m) (((m) >> 9) & 63)
+#define TSC_ITEM_SLOT(m) ((m) & 511)
 
-struct DriveShared {
-  unsigned short meta[TSC_NQ][TSC_QCAP]; // (replica within block << 10) | slot
+struct DriveCtx { // wave-uniform constants of the drivable a workgroup deals with
+  int d, sb, rb, end_lane, qb, qe;
+  double L, drvMax, interval;
+};
+struct ReplicaShared { // per-replica values of the block's 64 replicas (LDS)
   unsigned long long oe[64], ov[64], osg[64];
-  int raw[64], vbase[64], ob_cnt[64], ob_slot[64][TSC_OB_MAX];
+  int raw[64], vbase[64];
 };
 
-template <bool SINGLE, bool IS_LINK>
-__global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
-  __shared__ DriveShared sh;
-  int rb, row;
-  if (!map_block(n_rb, n_rows, rb, row)) return;
-  row = __builtin_amdgcn_readfirstlane(row);
-  const int lane = threadIdx.x;
-  const int r_own = rb * 64 + lane;
-  const bool own_valid = r_own < S.R;
-  const int d = IS_LINK ? N.n_lanes + row : row;
-  const double interval = C.interval;
-  const double L = N.drv_length[d];
-  const double drvMax = N.drv_max_speed[d];
-  const int sb = N.drv_slot_base[d];
-  const int end_lane = IS_LINK ? N.link_end_lane[row] : -1;
-  const int qb = IS_LINK ? 0 : N.lane_out_ptr[d], qe = IS_LINK ? 0 : N.lane_out_ptr[d + 1];
-  // the signal that owns this lane's end / this link (wave-uniform); -1: lane ends at a virtual node
-  const int ag = IS_LINK ? N.link_agent[row] : (qb < qe ? N.link_agent[N.lane_out_links[qb] - N.n_lanes] : -1);
+template <bool SINGLE>
+__device__ __forceinline__ void load_replica_shared(const DevNet &N, const DevState &S, ReplicaShared &rs, int ag,
+                                                    int lane, int r_own, bool needed) {
+  const int r = r_own;
+  int raw = 0;
+  unsigned long long oe = 0, ov = 0, osg = 0;
+  if (ag >= 0 && needed) {
+    raw = S.raw_phase[IDX(ag)];
+    oe = S.occ_e[IDX(ag)];
+    ov = S.occ_v[IDX(ag)];
+    // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
+    osg = S.occ_s[IDX(ag)] & N.agent_phase_avail[(size_t)ag * 32 + raw];
+  }
+  rs.raw[lane] = raw;
+  rs.oe[lane] = oe;
+  rs.ov[lane] = ov;
+  rs.osg[lane] = osg;
+  rs.vbase[lane] = (SINGLE || !needed) ? 0 : N.set_veh_ptr[S.set[r]];
+}
+
+// ---- a plain follower (item: replica rl of the block, slot it >= 1)
+template <bool SINGLE>
+__device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, const DriveCtx &ctx, bool valid,
+                                            int rl, int it, bool is_tail, int vbase) {
+  const int d = ctx.d, sb = ctx.sb;
+  const double L = ctx.L, drvMax = ctx.drvMax, interval = ctx.interval;
   const double *__restrict__ g_dist = S.dist;
   const double *__restrict__ g_speed = S.speed;
   const int *__restrict__ g_tag = S.tag;
-  const int *__restrict__ g_aux = S.aux;
   double *__restrict__ o_dist = S.ndist;
   double *__restrict__ o_speed = S.nspeed;
-
-  int n = 0;
-  {
-    const int r = own_valid ? r_own : 0;
-    if (own_valid) n = S.cnt[IDX(d)] & TSC_CNT_MASK;
-    int raw = 0;
-    unsigned long long oe = 0, ov = 0, osg = 0;
-    if (ag >= 0 && n > 0) {
-      raw = S.raw_phase[IDX(ag)];
-      oe = S.occ_e[IDX(ag)];
-      ov = S.occ_v[IDX(ag)];
-      // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
-      osg = S.occ_s[IDX(ag)] & N.agent_phase_avail[(size_t)ag * 32 + raw];
-    }
-    sh.raw[lane] = raw;
-    sh.oe[lane] = oe;
-    sh.ov[lane] = ov;
-    sh.osg[lane] = osg;
-    sh.vbase[lane] = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
-    sh.ob_cnt[lane] = 0;
-  }
-  if (!__builtin_amdgcn_ballot_w64(n > 0)) { // nothing on this drivable in any of the 64 replicas
-    if (own_valid) {
-      const int r = r_own;
-      S.ob[IDX(d)] = 0;
-    }
-    return;
-  }
-  __syncthreads();
-
-  // loop invariants of the enumeration, hoisted by hand (the compiler must assume the
-  // stores inside the loop may alias the tables)
-  int olk[TSC_MAXQ];
-#pragma unroll
-  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (!IS_LINK && qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
-  const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
-  // wave-uniform queue state: H queues [0, TSC_MAXQ) -- lanes: one per out-link, so that
-  // a batch deals with ONE lane-link (uniform cross table, coalesced header loads);
-  // links and vehicles without a next link use queue 0 -- and the follower queue TSC_QF
-  int head[TSC_NQ], count[TSC_NQ];
-#pragma unroll
-  for (int q = 0; q < TSC_NQ; q++) head[q] = count[q] = 0;
-  double p_dist = 0, p_speed = 0;
-  int p_tmpl = 0;
-  int i = 0;
-  bool more = true;
-  // software pipeline of the enumeration: TSC_EU slots per turn, the next TSC_EU in flight
-  double c_dist[TSC_EU], c_speed[TSC_EU];
-  int c_blk[TSC_EU], c_tag[TSC_EU], c_aux[TSC_EU];
-#pragma unroll
-  for (int u = 0; u < TSC_EU; u++) {
-    c_dist[u] = 0;
-    c_speed[u] = 0;
-    c_blk[u] = 0;
-    c_tag[u] = 0;
-    c_aux[u] = -1;
-  }
-#pragma unroll
-  for (int u = 0; u < TSC_EU; u++)
-    if (u < n) {
-      const int r = r_own;
-      c_dist[u] = g_dist[SIDX(sb + u)];
-      c_speed[u] = g_speed[SIDX(sb + u)];
-      c_blk[u] = S.blk[SIDX(sb + u)];
-      if (!IS_LINK) c_aux[u] = g_aux[SIDX(sb + u)];
-      if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + u)];
-    }
-  for (;;) {
-    int pick = -1;
-#pragma unroll
-    for (int q = 0; q < TSC_NQ; q++)
-      if (pick < 0 && count[q] >= 64) pick = q;
-    if (pick < 0 && !more) {
-#pragma unroll
-      for (int q = 0; q < TSC_NQ; q++)
-        if (pick < 0 && count[q] > 0) pick = q;
-      if (pick < 0) break;
-    }
-    if (pick < 0) {
-      // ------------------------------------------------ (1) enumerate slots i .. i+TSC_EU-1
-      double dist2[TSC_EU], speed2[TSC_EU];
-      int blk2[TSC_EU], tag2[TSC_EU], aux2[TSC_EU];
-#pragma unroll
-      for (int u = 0; u < TSC_EU; u++) {
-        dist2[u] = c_dist[u];
-        speed2[u] = c_speed[u];
-        blk2[u] = c_blk[u];
-        tag2[u] = c_tag[u];
-        aux2[u] = c_aux[u];
-      }
-#pragma unroll
-      for (int u = 0; u < TSC_EU; u++)
-        if (i + TSC_EU + u < n) {
-          const int r = r_own;
-          c_dist[u] = g_dist[SIDX(sb + i + TSC_EU + u)];
-          c_speed[u] = g_speed[SIDX(sb + i + TSC_EU + u)];
-          c_blk[u] = S.blk[SIDX(sb + i + TSC_EU + u)];
-          if (!IS_LINK) c_aux[u] = g_aux[SIDX(sb + i + TSC_EU + u)];
-          if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + TSC_EU + u)];
-        }
-#pragma unroll
-      for (int u = 0; u < TSC_EU; u++) {
-        const int is = i + u;
-        const bool active = is < n;
-        const double dist = dist2[u], speed = speed2[u];
-        const int blkw = blk2[u];
-        int tid = 0, bucket = -1;
-        if (active) {
-          tid = SINGLE ? 0 : N.veh_tmpl[sh.vbase[lane] + TSC_TAG_VID(tag2[u])];
-          const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
-          const bool heavy = IS_LINK || is == 0 || (L - dist) <= approach;
-          bucket = TSC_QF;
-          if (heavy) {
-            bucket = 0;
-            if (!IS_LINK) {
-#pragma unroll
-              for (int qq = 1; qq < TSC_MAXQ; qq++)
-                if (olk[qq] == aux2[u]) bucket = qq;
-            }
-          }
-          if (!IS_LINK && is > 0 && speed == 0 && p_speed == 0) {
-            // A lane vehicle stopped behind a stopped leader within minGap: both
-            // no-collision bounds are negative whatever the signal or the crosses say, so
-            // v = 0 and the position is unchanged -- no arithmetic needed.  (The blocker
-            // the engine would note for it is never read: only lane heads, vehicles on
-            // lane-links and fresh tails are ever registered at a cross.)
-            const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
-            const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
-            if (p_dist - plen - dist <= mg) {
-              const int r = r_own;
-              bucket = -1;
-              if (blkw != 0) { // let an earlier blocker entry expire
-                S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
-                S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
-              }
-              o_dist[SIDX(sb + is)] = dist;
-              o_speed[SIDX(sb + is)] = 0.0;
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < TSC_NQ; q++) {
-          if (IS_LINK && q != 0) continue;
-          if (!IS_LINK && q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
-          const bool put = bucket == q;
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
-          if (m) {
-            const int rank =
-                __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (put) sh.meta[q][(head[q] + count[q] + rank) & TSC_QMASK] = (unsigned short)((lane << 10) | is);
-            count[q] += __builtin_popcountll(m);
-          }
-        }
-        p_dist = dist;
-        p_speed = speed;
-        p_tmpl = tid;
-      }
-      i += TSC_EU;
-      more = __builtin_amdgcn_ballot_w64(i < n) != 0;
-      continue;
-    }
-    __syncthreads();
-    if (C.ablate & 256) {
-#pragma unroll
-      for (int q = 0; q < TSC_NQ; q++) count[q] = 0;
-      continue;
-    }
-    // pop one batch from queue `pick` (wave-uniform)
-    int nb = 0, meta = 0;
-#pragma unroll
-    for (int q = 0; q < TSC_NQ; q++)
-      if (q == pick) {
-        nb = count[q] < 64 ? count[q] : 64;
-        meta = sh.meta[q][(head[q] + lane) & TSC_QMASK];
-        head[q] = (head[q] + nb) & TSC_QMASK;
-        count[q] -= nb;
-      }
-    const bool valid = lane < nb;
-    const int rl = valid ? (meta >> 10) : lane; // replica of the item within this block
-    const int it = valid ? (meta & 1023) : 0;
-    const int r = rb * 64 + rl;
-    const int vbase = sh.vbase[rl];
-    if (pick == TSC_QF) {
-      // ------------------------------------------------ (2a) plain followers
-      if (valid) {
+  if (valid) {
+    const int r = ctx.rb * 64 + rl;
         const double dist = g_dist[SIDX(sb + it)], speed = g_speed[SIDX(sb + it)];
         const double pd = g_dist[SIDX(sb + it - 1)], vL = g_speed[SIDX(sb + it - 1)];
         const int blkw = S.blk[SIDX(sb + it)];
@@ -631,18 +466,43 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
         o_dist[SIDX(sb + it)] = nd;
         o_speed[SIDX(sb + it)] = v;
+        if (is_tail) {
+          S.ntail_dist[IDX(d)] = nd;
+          S.ntail_speed[IDX(d)] = v;
+        }
       }
-      __syncthreads();
-      continue;
-    }
-    // -------------------------------------------------- (2b) head / near the lane end / on a lane-link
-    {
+
+}
+
+// ---- head / near the lane end / on a lane-link (item: replica rl of the block, slot it);
+//      lanes: `pick` = index of the out-link all items of this batch are heading for
+template <bool SINGLE, bool IS_LINK>
+__device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, const DevCfg &C, const DriveCtx &ctx,
+                                           int ag, const int (&olk)[TSC_MAXQ], int pick, bool valid, int rl, int it,
+                                           bool is_tail) {
+  const int d = ctx.d, sb = ctx.sb, end_lane = ctx.end_lane, qb = ctx.qb, qe = ctx.qe;
+  const double L = ctx.L, drvMax = ctx.drvMax, interval = ctx.interval;
+  const int r = ctx.rb * 64 + rl;
+  const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
+  const double *__restrict__ g_dist = S.dist;
+  const double *__restrict__ g_speed = S.speed;
+  const int *__restrict__ g_tag = S.tag;
+  const int *__restrict__ g_aux = S.aux;
+  double *__restrict__ o_dist = S.ndist;
+  double *__restrict__ o_speed = S.nspeed;
       // the lane-link this batch deals with (wave-uniform); lanes: out-link `pick`
       const int link = IS_LINK ? d : (qb + pick < qe ? N.lane_out_links[qb + pick] : -1);
       const int lk = link >= 0 ? link - N.n_lanes : 0;
       const int el = IS_LINK ? end_lane : (link >= 0 ? N.link_end_lane[lk] : 0);
-      const int raw = sh.raw[rl];
-      const unsigned long long oe = sh.oe[rl], ov = sh.ov[rl], os_green = sh.osg[rl];
+      // signal phase and cross-candidate masks of the item's replica: loaded with the item
+      int raw = 0;
+      unsigned long long oe = 0, ov = 0, os_green = 0;
+      if (valid && ag >= 0) {
+        raw = S.raw_phase[IDX(ag)];
+        oe = S.occ_e[IDX(ag)];
+        ov = S.occ_v[IDX(ag)];
+        os_green = S.occ_s[IDX(ag)];
+      }
       // ---- ONE load group: the item and its list predecessor, the header of the own
       //      link's end lane (look-ahead, canEnter) and, for head vehicles, the tails of all
       //      out-links (look-ahead).  Addresses depend only on (replica, slot) and
@@ -687,6 +547,8 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         }
       }
       const bool has_link = IS_LINK ? false : (valid && aux >= 0); // then aux == link (bucketed)
+      // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
+      if (ag >= 0) os_green &= N.agent_phase_avail[(size_t)ag * 32 + raw];
       const double my_len = link >= 0 ? N.drv_length[link] : 0.0;
       const int vid = TSC_TAG_VID(tag);
       const int tid = tmpl_of<SINGLE>(N, vbase, vid);
@@ -817,10 +679,10 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         double nd = deltaDis + dist;
         if (nd > L) {
           nd -= L;
-          int ko = atomicAdd(&sh.ob_cnt[rl], 1);
+          int ko = atomicAdd(&S.ob[IDX(d)], 1);
           if (ko < TSC_OB_MAX) {
-            sh.ob_slot[rl][ko] = it;
             size_t ox = ((size_t)d * TSC_OB_MAX + ko) * (size_t)S.RS + (size_t)r;
+            S.obx_slot[ox] = it;
             S.obx_tag[ox] = tag;
             S.obx_aux[ox] = aux; // lane vehicle with aux < 0: leaves the network
             S.obx_blk[ox] = new_w;
@@ -830,24 +692,285 @@ __global__ __launch_bounds__(64, 4) void k_drive(DevNet N, DevState S, DevCfg C,
         }
         o_dist[SIDX(sb + it)] = nd;
         o_speed[SIDX(sb + it)] = v;
+        if (is_tail) { // next tail record of a drivable that stays quiet (k_commit redoes it otherwise)
+          S.ntail_dist[IDX(d)] = nd;
+          S.ntail_speed[IDX(d)] = v;
+        }
       }
-      __syncthreads();
+
+}
+
+// wave-uniform enumeration helpers --------------------------------------------------
+struct EnumQueues { // H lists in LDS (k_drive_link) or the follower queue (k_enum)
+  unsigned short item[TSC_QCAP];
+};
+
+// ------------------------------------------------------------------ k_enum (lanes)
+template <bool SINGLE>
+__global__ __launch_bounds__(64, 8) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+  __shared__ int sh_vbase[64];
+  int rb, row;
+  if (!map_block(n_rb, n_rows, rb, row)) return;
+  row = __builtin_amdgcn_readfirstlane(row);
+  const int lane = threadIdx.x;
+  const int r_own = rb * 64 + lane;
+  const bool own_valid = r_own < S.R;
+  DriveCtx ctx;
+  ctx.d = row;
+  ctx.rb = rb;
+  ctx.sb = N.drv_slot_base[row];
+  ctx.end_lane = -1;
+  ctx.qb = N.lane_out_ptr[row];
+  ctx.qe = N.lane_out_ptr[row + 1];
+  ctx.L = N.drv_length[row];
+  ctx.drvMax = N.drv_max_speed[row];
+  ctx.interval = C.interval;
+  const int d = row, sb = ctx.sb;
+  const double L = ctx.L;
+  int olk[TSC_MAXQ];
+#pragma unroll
+  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (ctx.qb + qq < ctx.qe) ? N.lane_out_links[ctx.qb + qq] : -2;
+  const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
+  const double *__restrict__ g_dist = S.dist;
+  const double *__restrict__ g_speed = S.speed;
+  const int *__restrict__ g_tag = S.tag;
+  const int *__restrict__ g_aux = S.aux;
+  double *__restrict__ o_dist = S.ndist;
+  double *__restrict__ o_speed = S.nspeed;
+  int n = 0;
+  {
+    const int r = own_valid ? r_own : 0;
+    if (own_valid) {
+      n = S.cnt[IDX(d)] & TSC_CNT_MASK;
+      S.ob[IDX(d)] = 0; // outbox of this sub-step (k_heavy appends with atomics)
     }
+    sh_vbase[lane] = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
+  }
+  // global H lists of this (lane, replica block)
+  const size_t hq0 = ((size_t)row * n_rb + rb) * TSC_NLIST;
+  int hcount[TSC_NLIST];
+#pragma unroll
+  for (int q = 0; q < TSC_NLIST; q++) hcount[q] = 0;
+  if (!__builtin_amdgcn_ballot_w64(n > 0)) {
+    if (lane < TSC_NLIST) S.hq_cnt[hq0 + lane] = 0;
+    return;
   }
   __syncthreads();
+  double p_dist = 0, p_speed = 0;
+  int p_tmpl = 0;
+  int i = 0;
+  bool more = true;
+  // software pipeline: TSC_EU slots per turn, the next TSC_EU in flight
+  double c_dist[TSC_EU], c_speed[TSC_EU];
+  int c_blk[TSC_EU], c_tag[TSC_EU], c_aux[TSC_EU];
+#pragma unroll
+  for (int u = 0; u < TSC_EU; u++) {
+    c_dist[u] = 0;
+    c_speed[u] = 0;
+    c_blk[u] = 0;
+    c_tag[u] = 0;
+    c_aux[u] = -1;
+    if (u < n) {
+      const int r = r_own;
+      c_dist[u] = g_dist[SIDX(sb + u)];
+      c_speed[u] = g_speed[SIDX(sb + u)];
+      c_blk[u] = S.blk[SIDX(sb + u)];
+      c_aux[u] = g_aux[SIDX(sb + u)];
+      if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + u)];
+    }
+  }
+  while (more) {
+    {
+      double dist2[TSC_EU], speed2[TSC_EU];
+      int blk2[TSC_EU], tag2[TSC_EU], aux2[TSC_EU];
+#pragma unroll
+      for (int u = 0; u < TSC_EU; u++) {
+        dist2[u] = c_dist[u];
+        speed2[u] = c_speed[u];
+        blk2[u] = c_blk[u];
+        tag2[u] = c_tag[u];
+        aux2[u] = c_aux[u];
+      }
+#pragma unroll
+      for (int u = 0; u < TSC_EU; u++)
+        if (i + TSC_EU + u < n) {
+          const int r = r_own;
+          c_dist[u] = g_dist[SIDX(sb + i + TSC_EU + u)];
+          c_speed[u] = g_speed[SIDX(sb + i + TSC_EU + u)];
+          c_blk[u] = S.blk[SIDX(sb + i + TSC_EU + u)];
+          c_aux[u] = g_aux[SIDX(sb + i + TSC_EU + u)];
+          if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + TSC_EU + u)];
+        }
+#pragma unroll
+      for (int u = 0; u < TSC_EU; u++) {
+        const int is = i + u;
+        const bool active = is < n;
+        const double dist = dist2[u], speed = speed2[u];
+        const int blkw = blk2[u];
+        int tid = 0, bucket = -1;
+        if (active) {
+          const int r = r_own;
+          tid = SINGLE ? 0 : N.veh_tmpl[sh_vbase[lane] + TSC_TAG_VID(tag2[u])];
+          const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
+          const bool heavy = is == 0 || (L - dist) <= approach;
+          bucket = TSC_MAXQ; // follower
+          if (heavy) {
+            bucket = 0;
+#pragma unroll
+            for (int qq = 1; qq < TSC_MAXQ; qq++)
+              if (olk[qq] == aux2[u]) bucket = qq;
+          }
+          if (is > 0 && speed == 0 && p_speed == 0) {
+            // A lane vehicle stopped behind a stopped leader within minGap: both
+            // no-collision bounds are negative whatever the signal or the crosses say, so
+            // v = 0 and the position is unchanged -- no arithmetic needed.  (The blocker
+            // the engine would note for it is never read: only lane heads, vehicles on
+            // lane-links and fresh tails are ever registered at a cross.)
+            const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+            const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
+            if (p_dist - plen - dist <= mg) {
+              bucket = -1;
+              if (blkw != 0) { // let an earlier blocker entry expire
+                S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+                S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
+              }
+              o_dist[SIDX(sb + is)] = dist;
+              o_speed[SIDX(sb + is)] = 0.0;
+              if (is == n - 1) {
+                S.ntail_dist[IDX(d)] = dist;
+                S.ntail_speed[IDX(d)] = 0.0;
+              }
+            }
+          }
+        }
+        const unsigned short item = TSC_ITEM(lane, is, is == n - 1);
+        if (__builtin_amdgcn_ballot_w64(bucket >= 0)) {
+#pragma unroll
+          for (int q = 0; q < TSC_NLIST; q++) {
+            if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
+            const bool put = bucket == q;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
+            if (m) {
+              const int rank =
+                  __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+              if (put) {
+                if (hcount[q] + rank < TSC_HCAP) S.hq_items[(hq0 + q) * TSC_HCAP + hcount[q] + rank] = item;
+                else atomicAdd(&S.errors[0], 1);
+              }
+              hcount[q] += __builtin_popcountll(m);
+            }
+          }
+        }
+        p_dist = dist;
+        p_speed = speed;
+        p_tmpl = tid;
+      }
+      i += TSC_EU;
+      more = __builtin_amdgcn_ballot_w64(i < n) != 0;
+    }
+  }
+  if (lane < TSC_NLIST) {
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < TSC_NLIST; q++)
+      if (lane == q) c = hcount[q] < TSC_HCAP ? hcount[q] : TSC_HCAP;
+    S.hq_cnt[hq0 + lane] = c;
+  }
+}
+
+// ----------------------------------------------------------------- k_heavy (lanes)
+template <bool SINGLE>
+__global__ __launch_bounds__(64, 4) void k_heavy(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+  int rb, rq;
+  if (!map_block(n_rb, n_rows, rb, rq)) return;
+  rq = __builtin_amdgcn_readfirstlane(rq);
+  const int row = rq / TSC_NLIST, pick = rq % TSC_NLIST;
+  const size_t hq = ((size_t)row * n_rb + rb) * TSC_NLIST + pick;
+  const int lane = threadIdx.x;
+  // the count and the first 64 items are independent loads: one round trip
+  const int total = S.hq_cnt[hq];
+  int meta = S.hq_items[hq * TSC_HCAP + lane];
+  if (total == 0) return;
+  DriveCtx ctx;
+  ctx.d = row;
+  ctx.rb = rb;
+  ctx.sb = N.drv_slot_base[row];
+  ctx.end_lane = -1;
+  ctx.qb = N.lane_out_ptr[row];
+  ctx.qe = N.lane_out_ptr[row + 1];
+  ctx.L = N.drv_length[row];
+  ctx.drvMax = N.drv_max_speed[row];
+  ctx.interval = C.interval;
+  int olk[TSC_MAXQ];
+#pragma unroll
+  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (ctx.qb + qq < ctx.qe) ? N.lane_out_links[ctx.qb + qq] : -2;
+  const int ag = ctx.qb < ctx.qe ? N.link_agent[N.lane_out_links[ctx.qb] - N.n_lanes] : -1;
+  for (int b = 0; b < total; b += 64) {
+    const bool valid = b + lane < total;
+    if (b > 0) meta = valid ? S.hq_items[hq * TSC_HCAP + b + lane] : 0;
+    const int rl = valid ? TSC_ITEM_LANE(meta) : lane;
+    if (pick == TSC_MAXQ) { // the plain followers of this lane
+      const int r = rb * 64 + rl;
+      exec_follow<SINGLE>(N, S, ctx, valid, rl, valid ? TSC_ITEM_SLOT(meta) : 1, valid && TSC_ITEM_TAIL(meta),
+                          (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]]);
+    } else {
+      exec_heavy<SINGLE, false>(N, S, C, ctx, ag, olk, pick, valid, rl, valid ? TSC_ITEM_SLOT(meta) : 0,
+                                valid && TSC_ITEM_TAIL(meta));
+    }
+  }
+}
+
+// -------------------------------------------------------------- k_drive_link (links)
+template <bool SINGLE>
+__global__ __launch_bounds__(64, 4) void k_drive_link(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+  __shared__ EnumQueues hqs;
+  int rb, row;
+  if (!map_block(n_rb, n_rows, rb, row)) return;
+  row = __builtin_amdgcn_readfirstlane(row);
+  const int lane = threadIdx.x;
+  const int r_own = rb * 64 + lane;
+  const bool own_valid = r_own < S.R;
+  DriveCtx ctx;
+  ctx.d = N.n_lanes + row;
+  ctx.rb = rb;
+  ctx.sb = N.drv_slot_base[ctx.d];
+  ctx.end_lane = N.link_end_lane[row];
+  ctx.qb = 0;
+  ctx.qe = 0;
+  ctx.L = N.drv_length[ctx.d];
+  ctx.drvMax = N.drv_max_speed[ctx.d];
+  ctx.interval = C.interval;
+  const int d = ctx.d;
+  int olk[TSC_MAXQ];
+#pragma unroll
+  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = -2;
+  int n = 0;
   if (own_valid) {
     const int r = r_own;
-    int m = sh.ob_cnt[lane];
-    if (m > TSC_OB_MAX) m = TSC_OB_MAX;
-    int ob = m;
-    for (int k = 0; k < m; k++) ob |= (sh.ob_slot[lane][k] & 1023) << (2 + 10 * k);
-    S.ob[IDX(d)] = ob;
-    // next tail record of a drivable that stays quiet (k_commit redoes it otherwise):
-    // the new position / speed of the last vehicle, written by this workgroup above
-    if (n > 0) {
-      S.ntail_dist[IDX(d)] = o_dist[SIDX(sb + n - 1)];
-      S.ntail_speed[IDX(d)] = o_speed[SIDX(sb + n - 1)];
+    n = S.cnt[IDX(d)] & TSC_CNT_MASK;
+    S.ob[IDX(d)] = 0;
+  }
+  if (!__builtin_amdgcn_ballot_w64(n > 0)) return;
+  const int ag = N.link_agent[row];
+  // every vehicle on a lane-link takes the full path: enumerate (slot numbers only), then execute
+  int count = 0;
+  for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) {
+    const bool put = i < n;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    if (put) {
+      if (count + rank < TSC_QCAP) hqs.item[count + rank] = TSC_ITEM(lane, i, i == n - 1);
+      else atomicAdd(&S.errors[0], 1);
     }
+    count += __builtin_popcountll(m);
+  }
+  if (count > TSC_QCAP) count = TSC_QCAP;
+  __syncthreads();
+  for (int b = 0; b < count; b += 64) {
+    const bool valid = b + lane < count;
+    const int meta = valid ? hqs.item[b + lane] : 0;
+    exec_heavy<SINGLE, true>(N, S, C, ctx, ag, olk, 0, valid, valid ? TSC_ITEM_LANE(meta) : lane,
+                             valid ? TSC_ITEM_SLOT(meta) : 0, valid && TSC_ITEM_TAIL(meta));
   }
 }
 
@@ -920,14 +1043,13 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       o_feed[q] = S.ob[IDX(f)];
     }
   const int n = hdr & TSC_CNT_MASK;
-  const int o_self = n > 0 ? o_raw : 0;
-  const int m_self = o_self & 3;
+  const int m_self = n > 0 ? (o_raw < TSC_OB_MAX ? o_raw : TSC_OB_MAX) : 0;
   // ---- is anything arriving?
   int n_arr = 0, first_f = -1; // arrivals, and the outbox (drivable, index) of the first one found
   int first_k = 0;
   if (is_link) {
     const int f = N.link_start_lane[d - N.n_lanes];
-    const int m = o_feed[0] & 3;
+    const int m = o_feed[0] < TSC_OB_MAX ? o_feed[0] : TSC_OB_MAX;
     for (int k = 0; k < m; k++) {
       size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
       if (S.obx_aux[ox] == d) {
@@ -942,12 +1064,13 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     // every vehicle leaving a feeder lane-link comes here
 #pragma unroll
     for (int q = 0; q < 4; q++)
-      if (fb + q < fe && (o_feed[q] & 3)) {
+      if (fb + q < fe && o_feed[q]) {
         if (n_arr == 0) first_f = N.lane_in_links[fb + q];
-        n_arr += o_feed[q] & 3;
+        n_arr += o_feed[q] < TSC_OB_MAX ? o_feed[q] : TSC_OB_MAX;
       }
     for (int q = fb + 4; q < fe; q++) {
-      int m = S.ob[IDX(N.lane_in_links[q])] & 3;
+      int m = S.ob[IDX(N.lane_in_links[q])];
+      if (m > TSC_OB_MAX) m = TSC_OB_MAX;
       if (m) {
         if (n_arr == 0) first_f = N.lane_in_links[q];
         n_arr += m;
@@ -967,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   if (m_self == 0 && !arrivals && !spawn_possible) {
     // quiet drivable: only the tail record moves (and the inserted-this-step bit clears)
-    // (its next tail record was written by k_drive)
+    // (its next tail record was written with the last vehicle's result)
     if (hdr & TSC_NEW_BIT) {
       S.tail_tag[IDX(d)] = S.tag[SIDX(sb + n - 1)];
       S.tail_prev[IDX(d)] = -1;
@@ -978,9 +1101,10 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   const int vbase = N.set_veh_ptr[S.set[r]];
   int tp = (hdr & TSC_NEW_BIT) ? -1 : S.tail_prev[IDX(d)];
   // ---- keep / retire
-  const int s0 = m_self > 0 ? ((o_self >> 2) & 1023) : -1;
-  const int s1 = m_self > 1 ? ((o_self >> 12) & 1023) : -1;
-  const int s2 = m_self > 2 ? ((o_self >> 22) & 1023) : -1;
+  const size_t oxs = (size_t)d * TSC_OB_MAX * (size_t)S.RS + (size_t)r;
+  const int s0 = m_self > 0 ? S.obx_slot[oxs] : -1;
+  const int s1 = m_self > 1 ? S.obx_slot[oxs + (size_t)S.RS] : -1;
+  const int s2 = m_self > 2 ? S.obx_slot[oxs + 2 * (size_t)S.RS] : -1;
   for (int k = 0; k < m_self; k++) {
     size_t ox = ((size_t)d * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
     if (!is_link && S.obx_aux[ox] < 0) { // left the network
@@ -1085,8 +1209,8 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       } else
       for (int q = fb; q < fe; q++) {
         int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
-        int o = S.ob[IDX(f)];
-        int m = o & 3;
+        int m = S.ob[IDX(f)];
+        if (m > TSC_OB_MAX) m = TSC_OB_MAX;
         for (int k = 0; k < m; k++) {
           size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
           int ax = S.obx_aux[ox];

@@ -17,7 +17,13 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 150):
 print("vehicles/replica", eng.mean_vehicles())
 eng.lib.tsc_debug_time_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 ms = C.c_double()
-for which, name in ((8, "notify"), (1, "lanes"), (2, "links"), (32, "commit(after)")):
-    for ab in ((0, 256, 8 << 16, 16 << 16, 32 << 16, (32 << 16) | 256) if which == 1 else (0,)):
-        eng.lib.tsc_debug_time_action(eng.h, ab, which, 5, C.byref(ms))
-        print(name, "ablate", ab, "us", round(ms.value * 1e3, 1))
+def t(which, ab=0, iters=5):
+    eng.lib.tsc_debug_time_action(eng.h, ab, which, iters, C.byref(ms))
+    return round(ms.value * 1e3, 1)
+
+print("notify", t(8), "enum", t(1), "enum(8rb)", t(1, 8 << 16), "commit", t(32))
+t(1, 0, 1)  # lists valid for k_heavy
+for ab in (0, 128, 64, 16, 1, 8 << 16, 16 << 16, 32 << 16):
+    print("heavy ablate", ab, "us", t(4, ab))
+for ab in (0, 128, 64, 16):
+    print("links ablate", ab, "us", t(2, ab))
