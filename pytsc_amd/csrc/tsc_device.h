@@ -20,6 +20,21 @@
 #define TSC_OB_MAX 3
 
 // One cross of a lane-link, 32 bytes so the wave-uniform scan fetches it with one scalar load.
+// Wave-uniform constants of one work list (k_enum -> k_exec), 128 bytes: everything a
+// batch needs about its drivable and the lane-link it is heading for, in one scalar load.
+struct ListRec {
+  int d, sb, pick, link;        // drivable, its slot base, out-link index (TSC_MAXQ: plain followers), lane-link or -1
+  int lk, el, ag, link_type;    // link - n_lanes, end lane of the link, agent, turn type
+  int olk[4];                   // lanes: the lane's out-links (-2: none)
+  int cross_b, cross_e;         // cross records of `link`
+  unsigned int avail_mask;      // raw phases in which `link` is green
+  int is_link;
+  double L, drvMax, my_len, first_cross_x; // drivable length / speed limit, length of `link`, its first cross
+  long long item_off;           // start of the list's items in wl_items
+  unsigned long long conflict;  // links of the intersection crossing `link`
+  long long pad[2];
+};
+
 struct CrossRec {
   double x;   // distance of the cross on this link
   double xo;  // distance of the cross on the other link
@@ -86,9 +101,14 @@ struct DevState {
   unsigned long long *fin_dsum, *fin_ssum; // sums over finished vehicles: duration, creation step
   // per vid [max_veh * RS]: committed blocker of a running vehicle, ping-pong halves
   int *bbv, *nbbv;
-  // work lists of k_enum for k_heavy: [(lane * n_rb + rb) * TSC_MAXQ + q] counts, * TSC_HCAP items
-  int *hq_cnt;
-  unsigned short *hq_items;
+  // work lists of k_enum for k_exec (all replicas): wl_nb[2] batch counts (lanes, links)
+  // followed in the same allocation by wl_cnt[n_lists]; both zeroed before every k_enum.
+  int *wl_nb;
+  int *wl_cnt;
+  const ListRec *wl_rec;   // [n_lists]
+  unsigned int *wl_items;
+  int2 *wl_desc;           // batch table: lanes from 0, lane-links from wl_desc_link0
+  long long wl_desc_link0;
   int *errors; // [4]: slot overflow, outbox overflow, bad action, other
 };
 

@@ -327,16 +327,15 @@ __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &
 // Resolve the cross conflicts of one vehicle on / approaching lane-link `link`
 // (wave-uniform): first cross ahead, in distance order, that it may not pass.
 template <bool SINGLE>
-__device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, int r, int vbase, int link, bool mine,
-                                           double speed, const Tm &t, int vid, int ell, double dts,
+__device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, int r, int vbase, const ListRec &lr,
+                                           bool mine, double speed, const Tm &t, int vid, int ell, double dts,
                                            unsigned long long oe, unsigned long long ov, unsigned long long os_green,
                                            double interval, double &s, int &nblk, int ablate = 0) {
-  const int k = link - N.n_lanes;
-  unsigned long long active = mine ? (N.link_conflict[k] & (oe | ov | os_green)) : 0ull;
+  unsigned long long active = mine ? (lr.conflict & (oe | ov | os_green)) : 0ull;
   if (!__builtin_amdgcn_ballot_w64(active != 0)) return; // wave-uniform early out
-  const int t1 = N.link_type[k];
+  const int t1 = lr.link_type;
   bool stop = active == 0;
-  const int cb = N.link_cross_ptr[k], ce = N.link_cross_ptr[k + 1];
+  const int cb = lr.cross_b, ce = lr.cross_e;
   CrossRec cur = N.cross_rec[cb]; // wave-uniform: one 32-byte scalar load per cross, fetched one ahead
   for (int e = cb; e < ce; e++) {
     const CrossRec nxt = N.cross_rec[e + 1];
@@ -388,53 +387,25 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 #define TSC_MAXQ 4  /* out-links of a lane (checked at create): one H list per out-link */
 #define TSC_HCAP 512 /* items per global work list */
 #define TSC_NLIST (TSC_MAXQ + 1) /* work lists per (lane, replica block): one per out-link + plain followers */
-#define TSC_ITEM(lane, slot, tail) ((unsigned short)(((tail) ? 0x8000 : 0) | ((lane) << 9) | (slot)))
-#define TSC_ITEM_TAIL(m) (((m) >> 15) & 1)
-#define TSC_ITEM_LANE(m) (((m) >> 9) & 63)
-#define TSC_ITEM_SLOT(m) ((m) & 511)
-
-struct DriveCtx { // wave-uniform constants of the drivable a workgroup deals with
-  int d, sb, rb, end_lane, qb, qe;
-  double L, drvMax, interval;
-};
-struct ReplicaShared { // per-replica values of the block's 64 replicas (LDS)
-  unsigned long long oe[64], ov[64], osg[64];
-  int raw[64], vbase[64];
-};
-
-template <bool SINGLE>
-__device__ __forceinline__ void load_replica_shared(const DevNet &N, const DevState &S, ReplicaShared &rs, int ag,
-                                                    int lane, int r_own, bool needed) {
-  const int r = r_own;
-  int raw = 0;
-  unsigned long long oe = 0, ov = 0, osg = 0;
-  if (ag >= 0 && needed) {
-    raw = S.raw_phase[IDX(ag)];
-    oe = S.occ_e[IDX(ag)];
-    ov = S.occ_v[IDX(ag)];
-    // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
-    osg = S.occ_s[IDX(ag)] & N.agent_phase_avail[(size_t)ag * 32 + raw];
-  }
-  rs.raw[lane] = raw;
-  rs.oe[lane] = oe;
-  rs.ov[lane] = ov;
-  rs.osg[lane] = osg;
-  rs.vbase[lane] = (SINGLE || !needed) ? 0 : N.set_veh_ptr[S.set[r]];
-}
+// work item: (replica << 10) | (slot << 1) | is-tail
+#define TSC_ITEM(rep, slot, tail) ((unsigned int)(((unsigned int)(rep) << 10) | ((slot) << 1) | ((tail) ? 1u : 0u)))
+#define TSC_ITEM_TAIL(m) ((m) & 1u)
+#define TSC_ITEM_REP(m) ((int)((m) >> 10))
+#define TSC_ITEM_SLOT(m) ((int)(((m) >> 1) & 511u))
 
 // ---- a plain follower (item: replica rl of the block, slot it >= 1)
 template <bool SINGLE>
-__device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, const DriveCtx &ctx, bool valid,
-                                            int rl, int it, bool is_tail, int vbase) {
-  const int d = ctx.d, sb = ctx.sb;
-  const double L = ctx.L, drvMax = ctx.drvMax, interval = ctx.interval;
+__device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, const ListRec &lr, double interval,
+                                            bool valid, int r, int it, bool is_tail) {
+  const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
+  const int d = lr.d, sb = lr.sb;
+  const double L = lr.L, drvMax = lr.drvMax;
   const double *__restrict__ g_dist = S.dist;
   const double *__restrict__ g_speed = S.speed;
   const int *__restrict__ g_tag = S.tag;
   double *__restrict__ o_dist = S.ndist;
   double *__restrict__ o_speed = S.nspeed;
   if (valid) {
-    const int r = ctx.rb * 64 + rl;
         const double dist = g_dist[SIDX(sb + it)], speed = g_speed[SIDX(sb + it)];
         const double pd = g_dist[SIDX(sb + it - 1)], vL = g_speed[SIDX(sb + it - 1)];
         const int blkw = S.blk[SIDX(sb + it)];
@@ -477,12 +448,10 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
 // ---- head / near the lane end / on a lane-link (item: replica rl of the block, slot it);
 //      lanes: `pick` = index of the out-link all items of this batch are heading for
 template <bool SINGLE, bool IS_LINK>
-__device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, const DevCfg &C, const DriveCtx &ctx,
-                                           int ag, const int (&olk)[TSC_MAXQ], int pick, bool valid, int rl, int it,
-                                           bool is_tail) {
-  const int d = ctx.d, sb = ctx.sb, end_lane = ctx.end_lane, qb = ctx.qb, qe = ctx.qe;
-  const double L = ctx.L, drvMax = ctx.drvMax, interval = ctx.interval;
-  const int r = ctx.rb * 64 + rl;
+__device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, const DevCfg &C, const ListRec &lr,
+                                           bool valid, int r, int it, bool is_tail) {
+  const int d = lr.d, sb = lr.sb, ag = lr.ag;
+  const double L = lr.L, drvMax = lr.drvMax, interval = C.interval;
   const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
   const double *__restrict__ g_dist = S.dist;
   const double *__restrict__ g_speed = S.speed;
@@ -491,9 +460,8 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
   double *__restrict__ o_dist = S.ndist;
   double *__restrict__ o_speed = S.nspeed;
       // the lane-link this batch deals with (wave-uniform); lanes: out-link `pick`
-      const int link = IS_LINK ? d : (qb + pick < qe ? N.lane_out_links[qb + pick] : -1);
-      const int lk = link >= 0 ? link - N.n_lanes : 0;
-      const int el = IS_LINK ? end_lane : (link >= 0 ? N.link_end_lane[lk] : 0);
+      const int link = lr.link;
+      const int el = lr.el;
       // signal phase and cross-candidate masks of the item's replica: loaded with the item
       int raw = 0;
       unsigned long long oe = 0, ov = 0, os_green = 0;
@@ -538,18 +506,18 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           l_tt[qq] = 0;
           l_td[qq] = 0;
           l_ts[qq] = 0;
-          if (olk[qq] >= 0 && valid && it == 0) {
-            l_cnt[qq] = S.cnt[IDX(olk[qq])] & TSC_CNT_MASK;
-            l_td[qq] = S.tail_dist[IDX(olk[qq])];
-            l_ts[qq] = S.tail_speed[IDX(olk[qq])];
-            if (!SINGLE) l_tt[qq] = S.tail_tag[IDX(olk[qq])];
+          if (lr.olk[qq] >= 0 && valid && it == 0) {
+            l_cnt[qq] = S.cnt[IDX(lr.olk[qq])] & TSC_CNT_MASK;
+            l_td[qq] = S.tail_dist[IDX(lr.olk[qq])];
+            l_ts[qq] = S.tail_speed[IDX(lr.olk[qq])];
+            if (!SINGLE) l_tt[qq] = S.tail_tag[IDX(lr.olk[qq])];
           }
         }
       }
       const bool has_link = IS_LINK ? false : (valid && aux >= 0); // then aux == link (bucketed)
       // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
       if (ag >= 0) os_green &= N.agent_phase_avail[(size_t)ag * 32 + raw];
-      const double my_len = link >= 0 ? N.drv_length[link] : 0.0;
+      const double my_len = lr.my_len;
       const int vid = TSC_TAG_VID(tag);
       const int tid = tmpl_of<SINGLE>(N, vbase, vid);
       const Tm t = load_tm(N, tid);
@@ -580,7 +548,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           // all lane-links leaving this lane may overlap: nearest tail wins
 #pragma unroll
           for (int qq = 0; qq < TSC_MAXQ; qq++) {
-            if (qb + qq < qe && l_cnt[qq] > 0) {
+            if (lr.olk[qq] >= 0 && l_cnt[qq] > 0) {
               int tt = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(l_tt[qq]));
               double cg = dis + l_td[qq] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
               if (!has_leader || cg < gap) {
@@ -618,7 +586,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       if (IS_LINK) {
         double s = t.maxSpeed;
         if (!(C.ablate & 16))
-          cross_scan<SINGLE>(N, S, r, vbase, d, valid, speed, t, vid, aux, dist, oe, ov, os_green, interval, s, nblk,
+          cross_scan<SINGLE>(N, S, r, vbase, lr, valid, speed, t, vid, aux, dist, oe, ov, os_green, interval, s, nblk,
                              C.ablate);
         v = min2(v, s);
       } else {
@@ -627,7 +595,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           double s = t.maxSpeed;
           bool done = !related;
           if (related) {
-            const bool avail = (N.link_avail_mask[lk] >> raw) & 1u;
+            const bool avail = (lr.avail_mask >> raw) & 1u;
             bool can_enter;
             if ((e_hdr & TSC_CNT_MASK) == 0) can_enter = true;
             else if (e_hdr & TSC_NEW_BIT) can_enter = false; // tail is a vehicle inserted this step: dist 0, speed 0
@@ -640,7 +608,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
                 done = true;
               }
             }
-            if (!done && N.link_type[lk] != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
+            if (!done && lr.link_type != TSC_LINK_STRAIGHT) s = min2(s, t.turnSpeed);
           }
           // A non-head vehicle whose first cross lies beyond its braking distance after one
           // more acceleration step cannot be slowed by any cross (stop_before_speed would
@@ -648,15 +616,14 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           // (see the enumeration note): the scan is skipped.  Heads are always scanned.
           bool scan = !done;
           if (scan && it > 0 && link >= 0) {
-            const int cb = N.link_cross_ptr[lk];
-            if (cb < N.link_cross_ptr[lk + 1]) {
+            if (lr.cross_b < lr.cross_e) {
               const double nextSpeed = speed + t.maxPosAcc * interval;
               const double bd = (speed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / t.usualNegAcc / 2);
-              if (bd < N.cross_rec[cb].x + (L - dist) - t.yieldDist) scan = false;
+              if (bd < lr.first_cross_x + (L - dist) - t.yieldDist) scan = false;
             } else scan = false;
           }
           if (!(C.ablate & 16))
-            cross_scan<SINGLE>(N, S, r, vbase, link, scan, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green,
+            cross_scan<SINGLE>(N, S, r, vbase, lr, scan, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green,
                                interval, s, nblk, C.ablate);
           if (related) v = min2(v, s);
         }
@@ -700,36 +667,74 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
 
 }
 
-// wave-uniform enumeration helpers --------------------------------------------------
-struct EnumQueues { // H lists in LDS (k_drive_link) or the follower queue (k_enum)
-  unsigned short item[TSC_QCAP];
-};
+// Work lists: one per (lane, out-link), one per lane for its plain followers, one per
+// lane-link -- each spanning ALL replicas, so that execution batches are full whatever
+// the per-replica occupancy.  A k_enum wave stages its items in LDS and appends them 64
+// at a time (one atomicAdd and one coalesced 256-byte store per flush); the order inside
+// a list is irrelevant (Jacobi update).
+//   list index: lane l, queue q in [0, TSC_NLIST)  ->  l * TSC_NLIST + q
+//               lane-link k                          ->  n_lanes * TSC_NLIST + k
+//   storage of list i: wl_items[wl_off[i] .. wl_off[i+1]), sized for every slot of the
+//   drivable in every replica, so it cannot overflow.
+#define TSC_STAGE 128
+__device__ __forceinline__ void wl_flush(const DevState &S, int list, unsigned int *stage, int n) {
+  int base = 0;
+  if (threadIdx.x == 0) base = atomicAdd(&S.wl_cnt[list], n);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if ((int)threadIdx.x < n) S.wl_items[S.wl_rec[list].item_off + base + threadIdx.x] = stage[threadIdx.x];
+}
+// one wave per workgroup: __syncthreads() is a wave-local LDS fence here
+__device__ __forceinline__ void wl_put(const DevState &S, int list, unsigned int *stage, int &qn, bool put,
+                                       unsigned int item) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
+  if (!m) return;
+  const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+  if (put) stage[qn + rank] = item;
+  qn += __builtin_popcountll(m);
+  if (qn >= 64) {
+    __syncthreads();
+    wl_flush(S, list, stage, 64);
+    const unsigned int rest = stage[64 + threadIdx.x];
+    __syncthreads();
+    stage[threadIdx.x] = rest;
+    qn -= 64;
+  }
+}
 
-// ------------------------------------------------------------------ k_enum (lanes)
-template <bool SINGLE>
-__global__ __launch_bounds__(64, 8) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
-  __shared__ int sh_vbase[64];
+// ------------------------------------------------------------------ k_enum
+template <bool SINGLE, bool IS_LINK>
+__global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+  __shared__ unsigned int stage[IS_LINK ? 1 : TSC_NLIST][TSC_STAGE];
   int rb, row;
   if (!map_block(n_rb, n_rows, rb, row)) return;
   row = __builtin_amdgcn_readfirstlane(row);
   const int lane = threadIdx.x;
-  const int r_own = rb * 64 + lane;
-  const bool own_valid = r_own < S.R;
-  DriveCtx ctx;
-  ctx.d = row;
-  ctx.rb = rb;
-  ctx.sb = N.drv_slot_base[row];
-  ctx.end_lane = -1;
-  ctx.qb = N.lane_out_ptr[row];
-  ctx.qe = N.lane_out_ptr[row + 1];
-  ctx.L = N.drv_length[row];
-  ctx.drvMax = N.drv_max_speed[row];
-  ctx.interval = C.interval;
-  const int d = row, sb = ctx.sb;
-  const double L = ctx.L;
+  const int r = rb * 64 + lane;
+  const bool own_valid = r < S.R;
+  const int d = IS_LINK ? N.n_lanes + row : row;
+  const int sb = N.drv_slot_base[d];
+  const double L = N.drv_length[d];
+  const int wl0 = IS_LINK ? N.n_lanes * TSC_NLIST + row : row * TSC_NLIST;
+  int n = 0;
+  if (own_valid) {
+    n = S.cnt[IDX(d)] & TSC_CNT_MASK;
+    S.ob[IDX(d)] = 0; // outbox of this sub-step (the executors append with atomics)
+  }
+  if (!__builtin_amdgcn_ballot_w64(n > 0)) return;
+  if (IS_LINK) {
+    // every vehicle on a lane-link takes the full path
+    int qn = 0;
+    for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl0, stage[0], qn, i < n, TSC_ITEM(r, i, i == n - 1));
+    if (qn) {
+      __syncthreads();
+      wl_flush(S, wl0, stage[0], qn);
+    }
+    return;
+  }
+  const int qb = N.lane_out_ptr[d], qe = N.lane_out_ptr[d + 1];
   int olk[TSC_MAXQ];
 #pragma unroll
-  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (ctx.qb + qq < ctx.qe) ? N.lane_out_links[ctx.qb + qq] : -2;
+  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
   const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
   const double *__restrict__ g_dist = S.dist;
   const double *__restrict__ g_speed = S.speed;
@@ -737,29 +742,12 @@ __global__ __launch_bounds__(64, 8) void k_enum(DevNet N, DevState S, DevCfg C, 
   const int *__restrict__ g_aux = S.aux;
   double *__restrict__ o_dist = S.ndist;
   double *__restrict__ o_speed = S.nspeed;
-  int n = 0;
-  {
-    const int r = own_valid ? r_own : 0;
-    if (own_valid) {
-      n = S.cnt[IDX(d)] & TSC_CNT_MASK;
-      S.ob[IDX(d)] = 0; // outbox of this sub-step (k_heavy appends with atomics)
-    }
-    sh_vbase[lane] = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
-  }
-  // global H lists of this (lane, replica block)
-  const size_t hq0 = ((size_t)row * n_rb + rb) * TSC_NLIST;
-  int hcount[TSC_NLIST];
-#pragma unroll
-  for (int q = 0; q < TSC_NLIST; q++) hcount[q] = 0;
-  if (!__builtin_amdgcn_ballot_w64(n > 0)) {
-    if (lane < TSC_NLIST) S.hq_cnt[hq0 + lane] = 0;
-    return;
-  }
-  __syncthreads();
+  const int vbase = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
   double p_dist = 0, p_speed = 0;
   int p_tmpl = 0;
-  int i = 0;
-  bool more = true;
+  int qn[TSC_NLIST];
+#pragma unroll
+  for (int q = 0; q < TSC_NLIST; q++) qn[q] = 0;
   // software pipeline: TSC_EU slots per turn, the next TSC_EU in flight
   double c_dist[TSC_EU], c_speed[TSC_EU];
   int c_blk[TSC_EU], c_tag[TSC_EU], c_aux[TSC_EU];
@@ -771,7 +759,6 @@ __global__ __launch_bounds__(64, 8) void k_enum(DevNet N, DevState S, DevCfg C, 
     c_tag[u] = 0;
     c_aux[u] = -1;
     if (u < n) {
-      const int r = r_own;
       c_dist[u] = g_dist[SIDX(sb + u)];
       c_speed[u] = g_speed[SIDX(sb + u)];
       c_blk[u] = S.blk[SIDX(sb + u)];
@@ -779,198 +766,144 @@ __global__ __launch_bounds__(64, 8) void k_enum(DevNet N, DevState S, DevCfg C, 
       if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + u)];
     }
   }
-  while (more) {
-    {
-      double dist2[TSC_EU], speed2[TSC_EU];
-      int blk2[TSC_EU], tag2[TSC_EU], aux2[TSC_EU];
+  for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i += TSC_EU) {
+    double dist2[TSC_EU], speed2[TSC_EU];
+    int blk2[TSC_EU], tag2[TSC_EU], aux2[TSC_EU];
 #pragma unroll
-      for (int u = 0; u < TSC_EU; u++) {
-        dist2[u] = c_dist[u];
-        speed2[u] = c_speed[u];
-        blk2[u] = c_blk[u];
-        tag2[u] = c_tag[u];
-        aux2[u] = c_aux[u];
+    for (int u = 0; u < TSC_EU; u++) {
+      dist2[u] = c_dist[u];
+      speed2[u] = c_speed[u];
+      blk2[u] = c_blk[u];
+      tag2[u] = c_tag[u];
+      aux2[u] = c_aux[u];
+    }
+#pragma unroll
+    for (int u = 0; u < TSC_EU; u++)
+      if (i + TSC_EU + u < n) {
+        c_dist[u] = g_dist[SIDX(sb + i + TSC_EU + u)];
+        c_speed[u] = g_speed[SIDX(sb + i + TSC_EU + u)];
+        c_blk[u] = S.blk[SIDX(sb + i + TSC_EU + u)];
+        c_aux[u] = g_aux[SIDX(sb + i + TSC_EU + u)];
+        if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + TSC_EU + u)];
       }
 #pragma unroll
-      for (int u = 0; u < TSC_EU; u++)
-        if (i + TSC_EU + u < n) {
-          const int r = r_own;
-          c_dist[u] = g_dist[SIDX(sb + i + TSC_EU + u)];
-          c_speed[u] = g_speed[SIDX(sb + i + TSC_EU + u)];
-          c_blk[u] = S.blk[SIDX(sb + i + TSC_EU + u)];
-          c_aux[u] = g_aux[SIDX(sb + i + TSC_EU + u)];
-          if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + TSC_EU + u)];
+    for (int u = 0; u < TSC_EU; u++) {
+      const int is = i + u;
+      const bool active = is < n;
+      const double dist = dist2[u], speed = speed2[u];
+      const int blkw = blk2[u];
+      int tid = 0, bucket = -1;
+      if (active) {
+        tid = SINGLE ? 0 : N.veh_tmpl[vbase + TSC_TAG_VID(tag2[u])];
+        const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
+        const bool heavy = is == 0 || (L - dist) <= approach;
+        bucket = TSC_MAXQ; // plain follower
+        if (heavy) {
+          bucket = 0;
+#pragma unroll
+          for (int qq = 1; qq < TSC_MAXQ; qq++)
+            if (olk[qq] == aux2[u]) bucket = qq;
         }
-#pragma unroll
-      for (int u = 0; u < TSC_EU; u++) {
-        const int is = i + u;
-        const bool active = is < n;
-        const double dist = dist2[u], speed = speed2[u];
-        const int blkw = blk2[u];
-        int tid = 0, bucket = -1;
-        if (active) {
-          const int r = r_own;
-          tid = SINGLE ? 0 : N.veh_tmpl[sh_vbase[lane] + TSC_TAG_VID(tag2[u])];
-          const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
-          const bool heavy = is == 0 || (L - dist) <= approach;
-          bucket = TSC_MAXQ; // follower
-          if (heavy) {
-            bucket = 0;
-#pragma unroll
-            for (int qq = 1; qq < TSC_MAXQ; qq++)
-              if (olk[qq] == aux2[u]) bucket = qq;
-          }
-          if (is > 0 && speed == 0 && p_speed == 0) {
-            // A lane vehicle stopped behind a stopped leader within minGap: both
-            // no-collision bounds are negative whatever the signal or the crosses say, so
-            // v = 0 and the position is unchanged -- no arithmetic needed.  (The blocker
-            // the engine would note for it is never read: only lane heads, vehicles on
-            // lane-links and fresh tails are ever registered at a cross.)
-            const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
-            const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
-            if (p_dist - plen - dist <= mg) {
-              bucket = -1;
-              if (blkw != 0) { // let an earlier blocker entry expire
-                S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
-                S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
-              }
-              o_dist[SIDX(sb + is)] = dist;
-              o_speed[SIDX(sb + is)] = 0.0;
-              if (is == n - 1) {
-                S.ntail_dist[IDX(d)] = dist;
-                S.ntail_speed[IDX(d)] = 0.0;
-              }
+        if (is > 0 && speed == 0 && p_speed == 0) {
+          // A lane vehicle stopped behind a stopped leader within minGap: both
+          // no-collision bounds are negative whatever the signal or the crosses say, so
+          // v = 0 and the position is unchanged -- no arithmetic needed.  (The blocker
+          // the engine would note for it is never read: only lane heads, vehicles on
+          // lane-links and fresh tails are ever registered at a cross.)
+          const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+          const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
+          if (p_dist - plen - dist <= mg) {
+            bucket = -1;
+            if (blkw != 0) { // let an earlier blocker entry expire
+              S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+              S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
+            }
+            if (!(C.ablate & 512)) {
+            o_dist[SIDX(sb + is)] = dist;
+            o_speed[SIDX(sb + is)] = 0.0;
+            }
+            if (is == n - 1) {
+              S.ntail_dist[IDX(d)] = dist;
+              S.ntail_speed[IDX(d)] = 0.0;
             }
           }
         }
-        const unsigned short item = TSC_ITEM(lane, is, is == n - 1);
-        if (__builtin_amdgcn_ballot_w64(bucket >= 0)) {
-#pragma unroll
-          for (int q = 0; q < TSC_NLIST; q++) {
-            if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
-            const bool put = bucket == q;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
-            if (m) {
-              const int rank =
-                  __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-              if (put) {
-                if (hcount[q] + rank < TSC_HCAP) S.hq_items[(hq0 + q) * TSC_HCAP + hcount[q] + rank] = item;
-                else atomicAdd(&S.errors[0], 1);
-              }
-              hcount[q] += __builtin_popcountll(m);
-            }
-          }
-        }
-        p_dist = dist;
-        p_speed = speed;
-        p_tmpl = tid;
       }
-      i += TSC_EU;
-      more = __builtin_amdgcn_ballot_w64(i < n) != 0;
+      if (__builtin_amdgcn_ballot_w64(bucket >= 0)) {
+        const unsigned int item = TSC_ITEM(r, is, is == n - 1);
+#pragma unroll
+        for (int q = 0; q < TSC_NLIST; q++) {
+          if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
+          if (!(C.ablate & 256)) wl_put(S, wl0 + q, stage[IS_LINK ? 0 : q], qn[q], bucket == q, item);
+        }
+      }
+      p_dist = dist;
+      p_speed = speed;
+      p_tmpl = tid;
     }
   }
-  if (lane < TSC_NLIST) {
-    int c = 0;
-#pragma unroll
-    for (int q = 0; q < TSC_NLIST; q++)
-      if (lane == q) c = hcount[q] < TSC_HCAP ? hcount[q] : TSC_HCAP;
-    S.hq_cnt[hq0 + lane] = c;
-  }
-}
-
-// ----------------------------------------------------------------- k_heavy (lanes)
-template <bool SINGLE>
-__global__ __launch_bounds__(64, 4) void k_heavy(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
-  int rb, rq;
-  if (!map_block(n_rb, n_rows, rb, rq)) return;
-  rq = __builtin_amdgcn_readfirstlane(rq);
-  const int row = rq / TSC_NLIST, pick = rq % TSC_NLIST;
-  const size_t hq = ((size_t)row * n_rb + rb) * TSC_NLIST + pick;
-  const int lane = threadIdx.x;
-  // the count and the first 64 items are independent loads: one round trip
-  const int total = S.hq_cnt[hq];
-  int meta = S.hq_items[hq * TSC_HCAP + lane];
-  if (total == 0) return;
-  DriveCtx ctx;
-  ctx.d = row;
-  ctx.rb = rb;
-  ctx.sb = N.drv_slot_base[row];
-  ctx.end_lane = -1;
-  ctx.qb = N.lane_out_ptr[row];
-  ctx.qe = N.lane_out_ptr[row + 1];
-  ctx.L = N.drv_length[row];
-  ctx.drvMax = N.drv_max_speed[row];
-  ctx.interval = C.interval;
-  int olk[TSC_MAXQ];
-#pragma unroll
-  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (ctx.qb + qq < ctx.qe) ? N.lane_out_links[ctx.qb + qq] : -2;
-  const int ag = ctx.qb < ctx.qe ? N.link_agent[N.lane_out_links[ctx.qb] - N.n_lanes] : -1;
-  for (int b = 0; b < total; b += 64) {
-    const bool valid = b + lane < total;
-    if (b > 0) meta = valid ? S.hq_items[hq * TSC_HCAP + b + lane] : 0;
-    const int rl = valid ? TSC_ITEM_LANE(meta) : lane;
-    if (pick == TSC_MAXQ) { // the plain followers of this lane
-      const int r = rb * 64 + rl;
-      exec_follow<SINGLE>(N, S, ctx, valid, rl, valid ? TSC_ITEM_SLOT(meta) : 1, valid && TSC_ITEM_TAIL(meta),
-                          (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]]);
-    } else {
-      exec_heavy<SINGLE, false>(N, S, C, ctx, ag, olk, pick, valid, rl, valid ? TSC_ITEM_SLOT(meta) : 0,
-                                valid && TSC_ITEM_TAIL(meta));
-    }
-  }
-}
-
-// -------------------------------------------------------------- k_drive_link (links)
-template <bool SINGLE>
-__global__ __launch_bounds__(64, 4) void k_drive_link(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
-  __shared__ EnumQueues hqs;
-  int rb, row;
-  if (!map_block(n_rb, n_rows, rb, row)) return;
-  row = __builtin_amdgcn_readfirstlane(row);
-  const int lane = threadIdx.x;
-  const int r_own = rb * 64 + lane;
-  const bool own_valid = r_own < S.R;
-  DriveCtx ctx;
-  ctx.d = N.n_lanes + row;
-  ctx.rb = rb;
-  ctx.sb = N.drv_slot_base[ctx.d];
-  ctx.end_lane = N.link_end_lane[row];
-  ctx.qb = 0;
-  ctx.qe = 0;
-  ctx.L = N.drv_length[ctx.d];
-  ctx.drvMax = N.drv_max_speed[ctx.d];
-  ctx.interval = C.interval;
-  const int d = ctx.d;
-  int olk[TSC_MAXQ];
-#pragma unroll
-  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = -2;
-  int n = 0;
-  if (own_valid) {
-    const int r = r_own;
-    n = S.cnt[IDX(d)] & TSC_CNT_MASK;
-    S.ob[IDX(d)] = 0;
-  }
-  if (!__builtin_amdgcn_ballot_w64(n > 0)) return;
-  const int ag = N.link_agent[row];
-  // every vehicle on a lane-link takes the full path: enumerate (slot numbers only), then execute
-  int count = 0;
-  for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) {
-    const bool put = i < n;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(put);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    if (put) {
-      if (count + rank < TSC_QCAP) hqs.item[count + rank] = TSC_ITEM(lane, i, i == n - 1);
-      else atomicAdd(&S.errors[0], 1);
-    }
-    count += __builtin_popcountll(m);
-  }
-  if (count > TSC_QCAP) count = TSC_QCAP;
   __syncthreads();
-  for (int b = 0; b < count; b += 64) {
-    const bool valid = b + lane < count;
-    const int meta = valid ? hqs.item[b + lane] : 0;
-    exec_heavy<SINGLE, true>(N, S, C, ctx, ag, olk, 0, valid, valid ? TSC_ITEM_LANE(meta) : lane,
-                             valid ? TSC_ITEM_SLOT(meta) : 0, valid && TSC_ITEM_TAIL(meta));
+#pragma unroll
+  for (int q = 0; q < TSC_NLIST; q++)
+    if (qn[q]) wl_flush(S, wl0 + q, stage[IS_LINK ? 0 : q], qn[q]);
+}
+
+// ------------------------------------------------------------------ k_plan
+// One wave per list: turns the list's item count into batch descriptors (list, batch)
+// appended to the lane or lane-link batch table.
+template <bool IS_LINK>
+__global__ __launch_bounds__(64) void k_plan(DevNet N, DevState S) {
+  const int list = (IS_LINK ? N.n_lanes * TSC_NLIST : 0) + (int)blockIdx.x;
+  const int nb = (S.wl_cnt[list] + 63) >> 6;
+  if (nb == 0) return;
+  int base = 0;
+  if (threadIdx.x == 0) base = atomicAdd(&S.wl_nb[IS_LINK ? 1 : 0], nb);
+  base = __builtin_amdgcn_readfirstlane(base);
+  int2 *desc = S.wl_desc + (IS_LINK ? S.wl_desc_link0 : 0);
+  for (int j = threadIdx.x; j < nb; j += 64) desc[base + j] = make_int2(list, j);
+}
+
+// ------------------------------------------------------------------ k_exec
+// Persistent grid over the batch table: workgroup w takes batches w, w + G, ...
+template <bool SINGLE, bool IS_LINK>
+__global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) {
+  const int lane = threadIdx.x;
+  const int nb = S.wl_nb[IS_LINK ? 1 : 0];
+  const int2 *desc = S.wl_desc + (IS_LINK ? S.wl_desc_link0 : 0);
+  int b = blockIdx.x;
+  if (b >= nb) return;
+  // the descriptor and the items of the next batch are fetched while this one executes
+  int2 de = desc[b];
+  unsigned int item = 0;
+  int total = 0;
+  {
+    const int list = __builtin_amdgcn_readfirstlane(de.x), j = __builtin_amdgcn_readfirstlane(de.y);
+    total = S.wl_cnt[list];
+    if (j * 64 + lane < total) item = S.wl_items[S.wl_rec[list].item_off + j * 64 + lane];
+  }
+  while (true) {
+    const int list = __builtin_amdgcn_readfirstlane(de.x);
+    const int j = __builtin_amdgcn_readfirstlane(de.y);
+    const ListRec lr = S.wl_rec[list];
+    const bool valid = j * 64 + lane < total;
+    const unsigned int it_cur = item;
+    const int b2 = b + (int)gridDim.x;
+    if (b2 < nb) {
+      de = desc[b2];
+      const int list2 = __builtin_amdgcn_readfirstlane(de.x), j2 = __builtin_amdgcn_readfirstlane(de.y);
+      total = S.wl_cnt[list2];
+      item = (j2 * 64 + lane < total) ? S.wl_items[S.wl_rec[list2].item_off + j2 * 64 + lane] : 0u;
+    }
+    const bool skip = !IS_LINK && (((C.ablate & 1024) && lr.pick == TSC_MAXQ) || ((C.ablate & 2048) && lr.pick != TSC_MAXQ));
+    const int r = TSC_ITEM_REP(it_cur);
+    if (skip) {
+    } else if (!IS_LINK && lr.pick == TSC_MAXQ) {
+      exec_follow<SINGLE>(N, S, lr, C.interval, valid, r, valid ? TSC_ITEM_SLOT(it_cur) : 1, valid && TSC_ITEM_TAIL(it_cur));
+    } else {
+      exec_heavy<SINGLE, IS_LINK>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
+    }
+    if (b2 >= nb) break;
+    b = b2;
   }
 }
 

@@ -21,9 +21,27 @@ def t(which, ab=0, iters=5):
     eng.lib.tsc_debug_time_action(eng.h, ab, which, iters, C.byref(ms))
     return round(ms.value * 1e3, 1)
 
-print("notify", t(8), "enum", t(1), "enum(8rb)", t(1, 8 << 16), "commit", t(32))
-t(1, 0, 1)  # lists valid for k_heavy
-for ab in (0, 128, 64, 16, 1, 8 << 16, 16 << 16, 32 << 16):
-    print("heavy ablate", ab, "us", t(4, ab))
-for ab in (0, 128, 64, 16):
-    print("links ablate", ab, "us", t(2, ab))
+print("notify", t(8), "enum lanes", t(1), "enum links", t(2), "commit", t(32))
+for ab in (0, 256, 512, 768):
+    print("enum lanes ablate", ab, t(1, ab))
+t(3 | 64, 0, 1)  # lists and batch table valid for k_exec
+print("enum+plan", t(3 | 64))
+for ab in (0, 16, 1, 1024, 2048, 1024 + 16, 1024 + 1):
+    print("exec lanes ablate", ab, "us", t(4, ab))
+for ab in (0, 16):
+    print("exec links ablate", ab, "us", t(16, ab))
+
+import numpy as np
+t(3 | 64, 0, 1)
+buf_ = (C.c_int32 * 100000)()
+eng.lib.tsc_debug_read_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+n = eng.lib.tsc_debug_read_lists(eng.h, buf_, 100000)
+a = np.frombuffer(buf_, dtype=np.int32)[:n]
+nb = a[:2]; cnt = a[2:]
+nl = tables.n_lanes
+lane = cnt[: nl * 5].reshape(nl, 5)
+link = cnt[nl * 5:]
+print("batches lanes, links", nb, "n_lanes", nl, "n_links", len(link))
+print("items per q", lane.sum(0), "links", link.sum())
+print("batches per q", ((lane + 63) // 64).sum(0), "links", ((link + 63) // 64).sum())
+print("nonempty lists per q", (lane > 0).sum(0))
