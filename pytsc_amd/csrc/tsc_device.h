@@ -89,6 +89,7 @@ struct DevState {
   double *ntail_dist, *ntail_speed; // next half: written by k_drive (quiet drivables) / k_commit, then swapped in
   // per lane [n_lanes * RS]
   int *spawn_cur, *lane_n, *lane_q;
+  int *fz; // [lane][replica] k_enum's standing block: fa | fb << 16 (slots (fa, fb] are skipped)
   double *lane_sum;
   unsigned int *lane_in_bits, *lane_out_bits;
   // per agent [n_agents * RS]
@@ -104,6 +105,7 @@ struct DevState {
   // work lists of k_enum for k_exec (all replicas): wl_nb[2] batch counts (lanes, links)
   // followed in the same allocation by wl_cnt[n_lists]; both zeroed before every k_enum.
   int *wl_nb;
+  int n_lists;
   int *wl_cnt;
   const ListRec *wl_rec;   // [n_lists]
   unsigned int *wl_items;

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
   const bool live = map_block(n_rb, n_agents, rb, a);
   a = __builtin_amdgcn_readfirstlane(a);
   const int lx = threadIdx.x, wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  if (blockIdx.x == 0) // the work-list counters of the sub-step that starts here
+    for (int i = threadIdx.y * 64 + threadIdx.x; i < S.n_lists + 2; i += 64 * NOTIFY_WAVES) S.wl_nb[i] = 0;
   const int r = rb * 64 + lx;
   const bool mine = live && r < S.R;
   if (wy == 0) {
@@ -396,7 +398,7 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 // ---- a plain follower (item: replica rl of the block, slot it >= 1)
 template <bool SINGLE>
 __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, const ListRec &lr, double interval,
-                                            bool valid, int r, int it, bool is_tail) {
+                                            bool valid, int r, int it, bool is_tail, int ablate = 0) {
   const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
   const int d = lr.d, sb = lr.sb;
   const double L = lr.L, drvMax = lr.drvMax;
@@ -407,8 +409,13 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
   double *__restrict__ o_speed = S.nspeed;
   if (valid) {
         const double dist = g_dist[SIDX(sb + it)], speed = g_speed[SIDX(sb + it)];
-        const double pd = g_dist[SIDX(sb + it - 1)], vL = g_speed[SIDX(sb + it - 1)];
-        const int blkw = S.blk[SIDX(sb + it)];
+        double pd = dist + 10.0, vL = speed;
+        int blkw = 0;
+        if (!(ablate & 8192)) {
+          pd = g_dist[SIDX(sb + it - 1)];
+          vL = g_speed[SIDX(sb + it - 1)];
+          blkw = S.blk[SIDX(sb + it)];
+        }
         int tid = 0, ptid = 0;
         if (!SINGLE) {
           tid = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + it)])];
@@ -465,7 +472,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       // signal phase and cross-candidate masks of the item's replica: loaded with the item
       int raw = 0;
       unsigned long long oe = 0, ov = 0, os_green = 0;
-      if (valid && ag >= 0) {
+      if (valid && ag >= 0 && !(C.ablate & 32768)) {
         raw = S.raw_phase[IDX(ag)];
         oe = S.occ_e[IDX(ag)];
         ov = S.occ_v[IDX(ag)];
@@ -487,13 +494,13 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         tag = g_tag[SIDX(sb + it)];
         aux = g_aux[SIDX(sb + it)];
         blkw = S.blk[SIDX(sb + it)];
-        if (it > 0) {
+        if (it > 0 && !(C.ablate & 131072)) {
           pd = g_dist[SIDX(sb + it - 1)];
           ps = g_speed[SIDX(sb + it - 1)];
           if (!SINGLE) ptag = g_tag[SIDX(sb + it - 1)];
         }
       }
-      if (valid && (IS_LINK ? it == 0 : link >= 0)) {
+      if (valid && (IS_LINK ? it == 0 : link >= 0) && !(C.ablate & 65536)) {
         e_hdr = S.cnt[IDX(el)];
         e_td = S.tail_dist[IDX(el)];
         e_ts = S.tail_speed[IDX(el)];
@@ -506,7 +513,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           l_tt[qq] = 0;
           l_td[qq] = 0;
           l_ts[qq] = 0;
-          if (lr.olk[qq] >= 0 && valid && it == 0) {
+          if (lr.olk[qq] >= 0 && valid && it == 0 && !(C.ablate & 16384)) {
             l_cnt[qq] = S.cnt[IDX(lr.olk[qq])] & TSC_CNT_MASK;
             l_td[qq] = S.tail_dist[IDX(lr.olk[qq])];
             l_ts[qq] = S.tail_speed[IDX(lr.olk[qq])];
@@ -736,6 +743,15 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
 #pragma unroll
   for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
   const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
+  // which out-links are green in this replica (bit q): a head stopped at a red light is settled here
+  int green_bits = 0xf;
+  if (qb < qe && own_valid) {
+    const int raw = S.raw_phase[IDX(N.link_agent[olk[0] - N.n_lanes])];
+    green_bits = 0;
+#pragma unroll
+    for (int qq = 0; qq < TSC_MAXQ; qq++)
+      if (olk[qq] >= 0 && ((N.link_avail_mask[olk[qq] - N.n_lanes] >> raw) & 1u)) green_bits |= 1 << qq;
+  }
   const double *__restrict__ g_dist = S.dist;
   const double *__restrict__ g_speed = S.speed;
   const int *__restrict__ g_tag = S.tag;
@@ -743,8 +759,39 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
   double *__restrict__ o_dist = S.ndist;
   double *__restrict__ o_speed = S.nspeed;
   const int vbase = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
+  // ---- the standing block of this (lane, replica): slots (fa, fb] were settled in the
+  //      previous sub-step with an empty blocker word, behind slot fa which was settled
+  //      too.  Their committed state is therefore the one they had (speed 0, same place,
+  //      same leader state) and BOTH ping-pong halves already hold it: they are settled
+  //      again, without being read or written (the walk stays in slot lock-step across
+  //      the 64 replicas -- row loads stay coalesced -- the lanes inside their block are
+  //      just masked off).  Slot fa -- whose own leader may have moved -- is walked like
+  //      any other; k_commit drops the block when slots shift.
+  int fa = 0, fb = 0, fz = 0;
+  if (own_valid && !(C.ablate & 8)) {
+    fz = S.fz[IDX(d)];
+    fa = fz & 0xffff;
+    fb = fz >> 16;
+    if (fb >= n) fb = fa; // cannot happen (slots only shift with a reset of the block)
+  }
+  const int skip = fb > fa ? fb - fa : 0;
+  double f_dist = 0;
+  int f_tmpl = 0;
+  if (skip) {
+    f_dist = g_dist[SIDX(sb + fb)];
+    if (!SINGLE) f_tmpl = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + fb)])];
+    if (fb == n - 1) { // the tail record follows the last vehicle even when it stands
+      S.ntail_dist[IDX(d)] = f_dist;
+      S.ntail_speed[IDX(d)] = 0.0;
+    }
+  }
+#define TSC_WALKED(sl) ((sl) < n && !((sl) > fa && (sl) <= fb && skip))
   double p_dist = 0, p_speed = 0;
   int p_tmpl = 0;
+  // the first run of settled slots with an empty blocker word that reaches the old block
+  // (or the first such run when there is none): next sub-step's block
+  int run_a = -1, run_b = -1;
+  bool run_final = false;
   int qn[TSC_NLIST];
 #pragma unroll
   for (int q = 0; q < TSC_NLIST; q++) qn[q] = 0;
@@ -758,12 +805,13 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
     c_blk[u] = 0;
     c_tag[u] = 0;
     c_aux[u] = -1;
-    if (u < n) {
-      c_dist[u] = g_dist[SIDX(sb + u)];
-      c_speed[u] = g_speed[SIDX(sb + u)];
-      c_blk[u] = S.blk[SIDX(sb + u)];
-      c_aux[u] = g_aux[SIDX(sb + u)];
-      if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + u)];
+    if (TSC_WALKED(u)) {
+      const int sl = u;
+      c_dist[u] = g_dist[SIDX(sb + sl)];
+      c_speed[u] = g_speed[SIDX(sb + sl)];
+      c_blk[u] = S.blk[SIDX(sb + sl)];
+      c_aux[u] = g_aux[SIDX(sb + sl)];
+      if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + sl)];
     }
   }
   for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i += TSC_EU) {
@@ -779,21 +827,33 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
     }
 #pragma unroll
     for (int u = 0; u < TSC_EU; u++)
-      if (i + TSC_EU + u < n) {
-        c_dist[u] = g_dist[SIDX(sb + i + TSC_EU + u)];
-        c_speed[u] = g_speed[SIDX(sb + i + TSC_EU + u)];
-        c_blk[u] = S.blk[SIDX(sb + i + TSC_EU + u)];
-        c_aux[u] = g_aux[SIDX(sb + i + TSC_EU + u)];
-        if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + i + TSC_EU + u)];
+      if (TSC_WALKED(i + TSC_EU + u)) {
+        const int sl = i + TSC_EU + u;
+        c_dist[u] = g_dist[SIDX(sb + sl)];
+        c_speed[u] = g_speed[SIDX(sb + sl)];
+        c_blk[u] = S.blk[SIDX(sb + sl)];
+        c_aux[u] = g_aux[SIDX(sb + sl)];
+        if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + sl)];
       }
 #pragma unroll
     for (int u = 0; u < TSC_EU; u++) {
       const int is = i + u;
-      const bool active = is < n;
+      const bool active = TSC_WALKED(is);
       const double dist = dist2[u], speed = speed2[u];
       const int blkw = blk2[u];
       int tid = 0, bucket = -1;
       if (active) {
+        if (skip && is == fb + 1) {
+          // first slot behind the standing block: its leader is the block's last vehicle;
+          // the block joins the run that reaches it (or starts one behind a moving slot fa)
+          p_dist = f_dist;
+          p_speed = 0.0;
+          p_tmpl = f_tmpl;
+          if (!run_final) {
+            if (run_a < 0) run_a = fa + 1;
+            run_b = fb;
+          }
+        }
         tid = SINGLE ? 0 : N.veh_tmpl[vbase + TSC_TAG_VID(tag2[u])];
         const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
         const bool heavy = is == 0 || (L - dist) <= approach;
@@ -804,6 +864,18 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
           for (int qq = 1; qq < TSC_MAXQ; qq++)
             if (olk[qq] == aux2[u]) bucket = qq;
         }
+        bool settled = false;
+        if (u == 0 && is == 0 && speed == 0 && aux2[u] >= 0 && !((green_bits >> bucket) & 1) && !(C.ablate & 4096)) {
+          // The head of a lane standing at a red light, too close to the stop line to take
+          // one more acceleration step: the stop-line bound of getNextSpeed is 0 (its
+          // link is not available and it can brake), no cross is scanned (so no blocker),
+          // every other bound is clamped by it: v = 0 and the position is unchanged.
+          const Tm t = load_tm(N, tid);
+          const double rest = L - dist;
+          if (rest <= t.approach && !(min_brake_distance(speed, t) > rest) &&
+              stop_before_speed(speed, t, rest, C.interval) == 0.0)
+            settled = true;
+        }
         if (is > 0 && speed == 0 && p_speed == 0) {
           // A lane vehicle stopped behind a stopped leader within minGap: both
           // no-collision bounds are negative whatever the signal or the crosses say, so
@@ -812,20 +884,31 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
           // lane-links and fresh tails are ever registered at a cross.)
           const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
           const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
-          if (p_dist - plen - dist <= mg) {
-            bucket = -1;
-            if (blkw != 0) { // let an earlier blocker entry expire
-              S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
-              S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
-            }
-            if (!(C.ablate & 512)) {
+          if (p_dist - plen - dist <= mg) settled = true;
+        }
+        if (settled) {
+          bucket = -1;
+          if (blkw != 0) { // let an earlier blocker entry expire
+            S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+            S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
+          }
+          if (!(C.ablate & 512)) {
             o_dist[SIDX(sb + is)] = dist;
             o_speed[SIDX(sb + is)] = 0.0;
-            }
-            if (is == n - 1) {
-              S.ntail_dist[IDX(d)] = dist;
-              S.ntail_speed[IDX(d)] = 0.0;
-            }
+          }
+          if (is == n - 1) {
+            S.ntail_dist[IDX(d)] = dist;
+            S.ntail_speed[IDX(d)] = 0.0;
+          }
+        }
+        if (!run_final) {
+          if (settled && blkw == 0) {
+            if (run_a < 0) run_a = is;
+            run_b = is;
+          } else if (run_a >= 0 && (skip == 0 || is > fb)) {
+            run_final = true; // the run ended behind the old block (or there was none)
+          } else {
+            run_a = -1; // a run that ended before reaching the old block
           }
         }
       }
@@ -841,6 +924,16 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
       p_speed = speed;
       p_tmpl = tid;
     }
+  }
+#undef TSC_WALKED
+  if (own_valid) {
+    // a block whose walk ended inside it (fb == n - 1) is joined here
+    if (skip && fb == n - 1 && !run_final) {
+      if (run_a < 0) run_a = fa + 1;
+      run_b = fb;
+    }
+    const int nfz = (run_a >= 0 && run_b > run_a) ? (run_a | (run_b << 16)) : 0;
+    if (nfz != fz) S.fz[IDX(d)] = nfz;
   }
   __syncthreads();
 #pragma unroll
@@ -898,7 +991,8 @@ __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) 
     const int r = TSC_ITEM_REP(it_cur);
     if (skip) {
     } else if (!IS_LINK && lr.pick == TSC_MAXQ) {
-      exec_follow<SINGLE>(N, S, lr, C.interval, valid, r, valid ? TSC_ITEM_SLOT(it_cur) : 1, valid && TSC_ITEM_TAIL(it_cur));
+      exec_follow<SINGLE>(N, S, lr, C.interval, valid, r, valid ? TSC_ITEM_SLOT(it_cur) : 1, valid && TSC_ITEM_TAIL(it_cur),
+                          C.ablate);
     } else {
       exec_heavy<SINGLE, IS_LINK>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
     }
@@ -1048,6 +1142,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       atomicAdd(&S.fin_ssum[r], (unsigned long long)st0);
     }
   }
+  if (!is_link && m_self > 0) S.fz[IDX(d)] = 0; // slots shift: k_enum's standing block is void
   int w = 0;
   bool have_tail = false, old_tail_kept = false;
   double tl_dist = 0, tl_speed = 0;
@@ -1224,6 +1319,7 @@ __global__ __launch_bounds__(256) void k_reset(DevNet N, DevState S, DevCfg C, c
   int w = 0, has_new = 0;
   if (d < N.n_lanes) {
     S.spawn_cur[IDX(d)] = 0;
+    S.fz[IDX(d)] = 0;
     spawn_if_due<SINGLE>(N, S, S.dist, S.speed, r, d, N.drv_slot_base[d], 0, w, false, 0.0, 0, has_new);
   }
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);

@@ -26,7 +26,8 @@ for ab in (0, 256, 512, 768):
     print("enum lanes ablate", ab, t(1, ab))
 t(3 | 64, 0, 1)  # lists and batch table valid for k_exec
 print("enum+plan", t(3 | 64))
-for ab in (0, 16, 1, 1024, 2048, 1024 + 16, 1024 + 1):
+B = 1024 + 16
+for ab in (0, 1024, B, B + 16384, B + 32768, B + 65536, B + 131072, B + 16384 + 32768 + 65536 + 131072):
     print("exec lanes ablate", ab, "us", t(4, ab))
 for ab in (0, 16):
     print("exec links ablate", ab, "us", t(16, ab))
