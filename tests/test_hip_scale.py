@@ -105,3 +105,41 @@ def test_full_size_properties_4x4_r4096():
     assert 100 < mean_veh < 3000
     assert eng.errors() == 0
     eng.close()
+
+
+def test_congested_queues_match_oracle(oracle_lib):
+    """Heavy demand with long red phases: long standing queues, spill-back onto
+    lane-links, discharge waves -- the states in which k_enum settles vehicles without
+    arithmetic (stopped queue members, heads at a red light) and skips standing blocks.
+    Replicas get different action streams; vehicle lists are compared slot by slot."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(flow_rate=1500.0, n_flow_sets=2, sim_length=900)
+    R = 6
+    eng = VecEngine(_tables("syn_3x3", R, **kw))
+    orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
+    rng = np.random.default_rng(11)
+    out = orc.observe()
+    hold = np.zeros((R, 9), dtype=np.int32)
+    for s in range(150):
+        m = out.mask
+        # replica r changes its phases every 2 + 3 r steps: from quick cycling to very long reds
+        pick = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        for r in range(R):
+            if s % (2 + 3 * r) == 0:
+                hold[r] = pick[r]
+        acts = np.where(np.take_along_axis(m, hold[..., None], -1)[..., 0] > 0, hold, pick).astype(np.int32)
+        out = orc.step(acts)
+        buf = eng.step(torch.tensor(acts, device="cuda"))
+        assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+        assert np.array_equal(buf["stats"].cpu().numpy(), out.stats), s
+        assert np.array_equal(buf["local_reward64"].cpu().numpy(), out.local_reward64), s
+        if s % 10 == 9:
+            for r in range(R):
+                a, b = orc.snapshot(r), eng.snapshot(r)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (s, r)
+    assert eng.mean_vehicles() > 150  # the network did fill up
+    assert eng.errors() == 0 and orc.errors() == 0
+    eng.close()
