@@ -709,12 +709,14 @@ __device__ __forceinline__ void wl_put(const DevState &S, int list, unsigned int
 }
 
 // ------------------------------------------------------------------ k_enum
-template <bool SINGLE, bool IS_LINK>
+template <bool SINGLE>
 __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
-  __shared__ unsigned int stage[IS_LINK ? 1 : TSC_NLIST][TSC_STAGE];
+  __shared__ unsigned int stage[TSC_NLIST][TSC_STAGE];
   int rb, row;
   if (!map_block(n_rb, n_rows, rb, row)) return;
   row = __builtin_amdgcn_readfirstlane(row);
+  const bool IS_LINK = row >= N.n_lanes; // rows: the lanes, then the lane-links
+  if (IS_LINK) row -= N.n_lanes;
   const int lane = threadIdx.x;
   const int r = rb * 64 + lane;
   const bool own_valid = r < S.R;
@@ -943,26 +945,24 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
 
 // ------------------------------------------------------------------ k_plan
 // One wave per list: turns the list's item count into batch descriptors (list, batch)
-// appended to the lane or lane-link batch table.
-template <bool IS_LINK>
+// appended to the batch table.
 __global__ __launch_bounds__(64) void k_plan(DevNet N, DevState S) {
-  const int list = (IS_LINK ? N.n_lanes * TSC_NLIST : 0) + (int)blockIdx.x;
+  const int list = (int)blockIdx.x;
   const int nb = (S.wl_cnt[list] + 63) >> 6;
   if (nb == 0) return;
   int base = 0;
-  if (threadIdx.x == 0) base = atomicAdd(&S.wl_nb[IS_LINK ? 1 : 0], nb);
+  if (threadIdx.x == 0) base = atomicAdd(&S.wl_nb[0], nb);
   base = __builtin_amdgcn_readfirstlane(base);
-  int2 *desc = S.wl_desc + (IS_LINK ? S.wl_desc_link0 : 0);
-  for (int j = threadIdx.x; j < nb; j += 64) desc[base + j] = make_int2(list, j);
+  for (int j = threadIdx.x; j < nb; j += 64) S.wl_desc[base + j] = make_int2(list, j);
 }
 
 // ------------------------------------------------------------------ k_exec
 // Persistent grid over the batch table: workgroup w takes batches w, w + G, ...
-template <bool SINGLE, bool IS_LINK>
+template <bool SINGLE>
 __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) {
   const int lane = threadIdx.x;
-  const int nb = S.wl_nb[IS_LINK ? 1 : 0];
-  const int2 *desc = S.wl_desc + (IS_LINK ? S.wl_desc_link0 : 0);
+  const int nb = S.wl_nb[0];
+  const int2 *desc = S.wl_desc;
   int b = blockIdx.x;
   if (b >= nb) return;
   // the descriptor and the items of the next batch are fetched while this one executes
@@ -987,14 +987,16 @@ __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) 
       total = S.wl_cnt[list2];
       item = (j2 * 64 + lane < total) ? S.wl_items[S.wl_rec[list2].item_off + j2 * 64 + lane] : 0u;
     }
-    const bool skip = !IS_LINK && (((C.ablate & 1024) && lr.pick == TSC_MAXQ) || ((C.ablate & 2048) && lr.pick != TSC_MAXQ));
+    const bool skip = !lr.is_link && (((C.ablate & 1024) && lr.pick == TSC_MAXQ) || ((C.ablate & 2048) && lr.pick != TSC_MAXQ));
     const int r = TSC_ITEM_REP(it_cur);
     if (skip) {
-    } else if (!IS_LINK && lr.pick == TSC_MAXQ) {
+    } else if (lr.is_link) {
+      exec_heavy<SINGLE, true>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
+    } else if (lr.pick == TSC_MAXQ) {
       exec_follow<SINGLE>(N, S, lr, C.interval, valid, r, valid ? TSC_ITEM_SLOT(it_cur) : 1, valid && TSC_ITEM_TAIL(it_cur),
                           C.ablate);
     } else {
-      exec_heavy<SINGLE, IS_LINK>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
+      exec_heavy<SINGLE, false>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
     }
     if (b2 >= nb) break;
     b = b2;

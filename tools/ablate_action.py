@@ -21,19 +21,17 @@ def t(which, ab=0, iters=5):
     eng.lib.tsc_debug_time_action(eng.h, ab, which, iters, C.byref(ms))
     return round(ms.value * 1e3, 1)
 
-print("notify", t(8), "enum lanes", t(1), "enum links", t(2), "commit", t(32))
+print("notify", t(8), "enum", t(1), "commit", t(32))
 for ab in (0, 256, 512, 768):
     print("enum lanes ablate", ab, t(1, ab))
-t(3 | 64, 0, 1)  # lists and batch table valid for k_exec
-print("enum+plan", t(3 | 64))
+t(1 | 64, 0, 1)  # lists and batch table valid for k_exec
+print("enum+plan", t(1 | 64))
 B = 1024 + 16
 for ab in (0, 1024, B, B + 16384, B + 32768, B + 65536, B + 131072, B + 16384 + 32768 + 65536 + 131072):
     print("exec lanes ablate", ab, "us", t(4, ab))
-for ab in (0, 16):
-    print("exec links ablate", ab, "us", t(16, ab))
 
 import numpy as np
-t(3 | 64, 0, 1)
+t(1 | 64, 0, 1)
 buf_ = (C.c_int32 * 100000)()
 eng.lib.tsc_debug_read_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 n = eng.lib.tsc_debug_read_lists(eng.h, buf_, 100000)
