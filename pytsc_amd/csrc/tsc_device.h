@@ -77,9 +77,12 @@ struct DevState {
   int R, RS; // replicas, row stride (R rounded up to 64)
   int n_slots; // total vehicle slots per replica (rows of the tiled slot arrays)
   // per slot [S_total * RS]
-  double *dist, *speed;   // committed half (read by k_notify / k_action / k_measure)
-  double *ndist, *nspeed; // the other half: written by k_action, patched by k_commit, then swapped in
-  int *tag, *aux, *blk;   // blk: blocker word (TSC_BLK_*), updated in place
+  // One vehicle = {dist, speed} (16 bytes, ping-pong) + {aux, blk} (8 bytes) + tag (4 bytes), the
+  // last two in place: the walk of k_enum reads the first two, a settled vehicle costs one store.
+  double2 *ds;  // committed half (read by k_notify / k_enum / k_exec / k_measure)
+  double2 *nds; // the other half: written by k_enum / k_exec, patched by k_commit, then swapped in
+  int2 *ab;     // x: aux (next drivable / link entry time), y: blocker word (TSC_BLK_*)
+  int *tag;
   // per drivable [n_drv * RS]
   int *cnt, *ob, *tail_tag, *tail_prev;
   // outbox of this sub-step's leavers: ob = how many (appended with atomics), records [n_drv * TSC_OB_MAX * RS]

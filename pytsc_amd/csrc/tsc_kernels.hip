@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
       const int he = S.cnt[IDX(e)];
       const int tpv = S.tail_prev[IDX(e)];
       const int hs = S.cnt[IDX(sl)];
-      const int ax = S.aux[SIDX(N.drv_slot_base[sl])];
+      const int ax = S.ab[SIDX(N.drv_slot_base[sl])].x;
       if ((cl & TSC_CNT_MASK) > 0) ov |= bit;
       if ((he & TSC_CNT_MASK) > 0 && !(he & TSC_NEW_BIT) && tpv == link) oe |= bit;
       if ((hs & TSC_CNT_MASK) > 0 && ax == link) os |= bit;
@@ -230,15 +230,16 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
     int n = S.cnt[IDX(other)] & TSC_CNT_MASK;
     const int sb = N.drv_slot_base[other];
     for (int j = 0; j < n; j++) {
-      double dj = S.dist[SIDX(sb + j)];
+      const double2 vj = S.ds[SIDX(sb + j)];
+      double dj = vj.x;
       int tg = S.tag[SIDX(sb + j)];
       int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tg));
       double tlen = N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
       if (dj > xo && !(dj - xo - tlen <= 0)) continue; // rear already past the cross: next vehicle
       f.d2 = xo - dj;
-      f.speed = S.speed[SIDX(sb + j)];
+      f.speed = vj.y;
       f.vid = TSC_TAG_VID(tg);
-      f.ell = S.aux[SIDX(sb + j)];
+      f.ell = S.ab[SIDX(sb + j)].x;
       f.tmpl = tt;
       break;
     }
@@ -246,10 +247,11 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
   if (f.vid < 0 && (os_green & bit)) {
     const int sl = N.link_start_lane[k];
     const int s0 = N.drv_slot_base[sl];
-    double ds = S.dist[SIDX(s0)];
+    const double2 v0 = S.ds[SIDX(s0)];
+    double ds = v0.x;
     int tg = S.tag[SIDX(s0)];
     f.d2 = (N.drv_length[sl] - ds) + xo;
-    f.speed = S.speed[SIDX(s0)];
+    f.speed = v0.y;
     f.vid = TSC_TAG_VID(tg);
     f.tmpl = tmpl_of<SINGLE>(N, vbase, f.vid);
   }
@@ -402,24 +404,23 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
   const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
   const int d = lr.d, sb = lr.sb;
   const double L = lr.L, drvMax = lr.drvMax;
-  const double *__restrict__ g_dist = S.dist;
-  const double *__restrict__ g_speed = S.speed;
-  const int *__restrict__ g_tag = S.tag;
-  double *__restrict__ o_dist = S.ndist;
-  double *__restrict__ o_speed = S.nspeed;
+  const double2 *__restrict__ g_ds = S.ds;
+  double2 *__restrict__ o_ds = S.nds;
   if (valid) {
-        const double dist = g_dist[SIDX(sb + it)], speed = g_speed[SIDX(sb + it)];
+        const double2 own = g_ds[SIDX(sb + it)];
+        const double dist = own.x, speed = own.y;
         double pd = dist + 10.0, vL = speed;
         int blkw = 0;
         if (!(ablate & 8192)) {
-          pd = g_dist[SIDX(sb + it - 1)];
-          vL = g_speed[SIDX(sb + it - 1)];
-          blkw = S.blk[SIDX(sb + it)];
+          const double2 lead = g_ds[SIDX(sb + it - 1)];
+          pd = lead.x;
+          vL = lead.y;
+          blkw = S.ab[SIDX(sb + it)].y;
         }
         int tid = 0, ptid = 0;
         if (!SINGLE) {
-          tid = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + it)])];
-          ptid = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + it - 1)])];
+          tid = N.veh_tmpl[vbase + TSC_TAG_VID(S.tag[SIDX(sb + it)])];
+          ptid = N.veh_tmpl[vbase + TSC_TAG_VID(S.tag[SIDX(sb + it - 1)])];
         }
         const Tm t = load_tm(N, tid);
         const Tm tl = load_tm(N, ptid);
@@ -437,13 +438,12 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
           deltaDis = (speed + v) * interval / 2;
         }
         if (blkw != 0) { // let a blocker from the previous intersection expire
-          S.blk[SIDX(sb + it)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
-          S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + it)]))] = -1;
+          S.ab[SIDX(sb + it)].y = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+          S.nbbv[IDX(TSC_TAG_VID(S.tag[SIDX(sb + it)]))] = -1;
         }
         const double nd = deltaDis + dist;
         if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
-        o_dist[SIDX(sb + it)] = nd;
-        o_speed[SIDX(sb + it)] = v;
+        o_ds[SIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) {
           S.ntail_dist[IDX(d)] = nd;
           S.ntail_speed[IDX(d)] = v;
@@ -460,12 +460,8 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
   const int d = lr.d, sb = lr.sb, ag = lr.ag;
   const double L = lr.L, drvMax = lr.drvMax, interval = C.interval;
   const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
-  const double *__restrict__ g_dist = S.dist;
-  const double *__restrict__ g_speed = S.speed;
-  const int *__restrict__ g_tag = S.tag;
-  const int *__restrict__ g_aux = S.aux;
-  double *__restrict__ o_dist = S.ndist;
-  double *__restrict__ o_speed = S.nspeed;
+  const double2 *__restrict__ g_ds = S.ds;
+  double2 *__restrict__ o_ds = S.nds;
       // the lane-link this batch deals with (wave-uniform); lanes: out-link `pick`
       const int link = lr.link;
       const int el = lr.el;
@@ -489,15 +485,18 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       int e_hdr = 0, e_tt = 0;
       double e_td = 0, e_ts = 0;
       if (valid) {
-        dist = g_dist[SIDX(sb + it)];
-        speed = g_speed[SIDX(sb + it)];
-        tag = g_tag[SIDX(sb + it)];
-        aux = g_aux[SIDX(sb + it)];
-        blkw = S.blk[SIDX(sb + it)];
+        const double2 own = g_ds[SIDX(sb + it)];
+        const int2 om = S.ab[SIDX(sb + it)];
+        dist = own.x;
+        speed = own.y;
+        tag = S.tag[SIDX(sb + it)];
+        aux = om.x;
+        blkw = om.y;
         if (it > 0 && !(C.ablate & 131072)) {
-          pd = g_dist[SIDX(sb + it - 1)];
-          ps = g_speed[SIDX(sb + it - 1)];
-          if (!SINGLE) ptag = g_tag[SIDX(sb + it - 1)];
+          const double2 lead = g_ds[SIDX(sb + it - 1)];
+          pd = lead.x;
+          ps = lead.y;
+          if (!SINGLE) ptag = S.tag[SIDX(sb + it - 1)];
         }
       }
       if (valid && (IS_LINK ? it == 0 : link >= 0) && !(C.ablate & 65536)) {
@@ -647,7 +646,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         // ---- blocker bookkeeping: slot word in place, vid-indexed entry in the other half
         int old_b = TSC_BLK_VID(blkw);
         int new_w = ((nblk + 1) & 0xffffff) | ((old_b >= 0) ? (1 << 30) : 0);
-        if (new_w != blkw) S.blk[SIDX(sb + it)] = new_w;
+        if (new_w != blkw) S.ab[SIDX(sb + it)].y = new_w;
         if (nblk >= 0 || old_b >= 0 || TSC_BLK_OLDER(blkw)) S.nbbv[IDX(vid)] = nblk;
         // ---- move (engine: setDeltaDistance)
         double nd = deltaDis + dist;
@@ -664,8 +663,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
             S.obx_speed[ox] = v;
           } else atomicAdd(&S.errors[1], 1);
         }
-        o_dist[SIDX(sb + it)] = nd;
-        o_speed[SIDX(sb + it)] = v;
+        o_ds[SIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) { // next tail record of a drivable that stays quiet (k_commit redoes it otherwise)
           S.ntail_dist[IDX(d)] = nd;
           S.ntail_speed[IDX(d)] = v;
@@ -754,12 +752,8 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
     for (int qq = 0; qq < TSC_MAXQ; qq++)
       if (olk[qq] >= 0 && ((N.link_avail_mask[olk[qq] - N.n_lanes] >> raw) & 1u)) green_bits |= 1 << qq;
   }
-  const double *__restrict__ g_dist = S.dist;
-  const double *__restrict__ g_speed = S.speed;
-  const int *__restrict__ g_tag = S.tag;
-  const int *__restrict__ g_aux = S.aux;
-  double *__restrict__ o_dist = S.ndist;
-  double *__restrict__ o_speed = S.nspeed;
+  const double2 *__restrict__ g_ds = S.ds;
+  double2 *__restrict__ o_ds = S.nds;
   const int vbase = (SINGLE || !own_valid) ? 0 : N.set_veh_ptr[S.set[r]];
   // ---- the standing block of this (lane, replica): slots (fa, fb] were settled in the
   //      previous sub-step with an empty blocker word, behind slot fa which was settled
@@ -780,8 +774,8 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
   double f_dist = 0;
   int f_tmpl = 0;
   if (skip) {
-    f_dist = g_dist[SIDX(sb + fb)];
-    if (!SINGLE) f_tmpl = N.veh_tmpl[vbase + TSC_TAG_VID(g_tag[SIDX(sb + fb)])];
+    f_dist = g_ds[SIDX(sb + fb)].x;
+    if (!SINGLE) f_tmpl = N.veh_tmpl[vbase + TSC_TAG_VID(S.tag[SIDX(sb + fb)])];
     if (fb == n - 1) { // the tail record follows the last vehicle even when it stands
       S.ntail_dist[IDX(d)] = f_dist;
       S.ntail_speed[IDX(d)] = 0.0;
@@ -809,11 +803,13 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
     c_aux[u] = -1;
     if (TSC_WALKED(u)) {
       const int sl = u;
-      c_dist[u] = g_dist[SIDX(sb + sl)];
-      c_speed[u] = g_speed[SIDX(sb + sl)];
-      c_blk[u] = S.blk[SIDX(sb + sl)];
-      c_aux[u] = g_aux[SIDX(sb + sl)];
-      if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + sl)];
+      const double2 v_ = g_ds[SIDX(sb + sl)];
+      const int2 m_ = S.ab[SIDX(sb + sl)];
+      c_dist[u] = v_.x;
+      c_speed[u] = v_.y;
+      c_blk[u] = m_.y;
+      c_aux[u] = m_.x;
+      if (!SINGLE) c_tag[u] = S.tag[SIDX(sb + sl)];
     }
   }
   for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i += TSC_EU) {
@@ -831,11 +827,13 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
     for (int u = 0; u < TSC_EU; u++)
       if (TSC_WALKED(i + TSC_EU + u)) {
         const int sl = i + TSC_EU + u;
-        c_dist[u] = g_dist[SIDX(sb + sl)];
-        c_speed[u] = g_speed[SIDX(sb + sl)];
-        c_blk[u] = S.blk[SIDX(sb + sl)];
-        c_aux[u] = g_aux[SIDX(sb + sl)];
-        if (!SINGLE) c_tag[u] = g_tag[SIDX(sb + sl)];
+        const double2 v_ = g_ds[SIDX(sb + sl)];
+        const int2 m_ = S.ab[SIDX(sb + sl)];
+        c_dist[u] = v_.x;
+        c_speed[u] = v_.y;
+        c_blk[u] = m_.y;
+        c_aux[u] = m_.x;
+        if (!SINGLE) c_tag[u] = S.tag[SIDX(sb + sl)];
       }
 #pragma unroll
     for (int u = 0; u < TSC_EU; u++) {
@@ -891,12 +889,11 @@ __global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, 
         if (settled) {
           bucket = -1;
           if (blkw != 0) { // let an earlier blocker entry expire
-            S.blk[SIDX(sb + is)] = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
-            S.nbbv[IDX(TSC_TAG_VID(g_tag[SIDX(sb + is)]))] = -1;
+            S.ab[SIDX(sb + is)].y = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
+            S.nbbv[IDX(TSC_TAG_VID(S.tag[SIDX(sb + is)]))] = -1;
           }
           if (!(C.ablate & 512)) {
-            o_dist[SIDX(sb + is)] = dist;
-            o_speed[SIDX(sb + is)] = 0.0;
+            o_ds[SIDX(sb + is)] = make_double2(dist, 0.0);
           }
           if (is == n - 1) {
             S.ntail_dist[IDX(d)] = dist;
@@ -1005,7 +1002,7 @@ __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) 
 
 // ---------------------------------------------------------------- k_commit
 template <bool SINGLE>
-__device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S, double *q_dist, double *q_speed,
+__device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S, double2 *q_ds,
                                              int r, int d, int sb, int t_next, int &w, bool have_tail,
                                              double tail_dist, int tail_tmpl, int &has_new) {
   int set = S.set[r];
@@ -1028,11 +1025,9 @@ __device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S,
   }
   int route = N.veh_route[vbase + vid];
   int rb_ = N.route_ptr[route], re_ = N.route_ptr[route + 1];
-  q_dist[SIDX(sb + w)] = 0;
-  q_speed[SIDX(sb + w)] = 0;
+  q_ds[SIDX(sb + w)] = make_double2(0.0, 0.0);
   S.tag[SIDX(sb + w)] = TSC_MAKE_TAG(vid, 0);
-  S.aux[SIDX(sb + w)] = (rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1;
-  S.blk[SIDX(sb + w)] = 0;
+  S.ab[SIDX(sb + w)] = make_int2((rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1, 0);
   S.bbv[IDX(vid)] = -1;
   S.nbbv[IDX(vid)] = -1;
   S.spawn_cur[IDX(d)] = c + 1;
@@ -1051,8 +1046,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   const int sb = N.drv_slot_base[d];
   const int cap = N.drv_cap[d];
   // the half k_action just wrote: it becomes the committed state after this kernel
-  double *__restrict__ q_dist = S.ndist;
-  double *__restrict__ q_speed = S.nspeed;
+  double2 *__restrict__ q_ds = S.nds;
   // ---- everything the quiet test needs is loaded up front, in one round trip
   int fb, fe;
   if (is_link) {
@@ -1154,8 +1148,9 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     if (n > 0) {
       have_tail = true;
       old_tail_kept = true;
-      tl_dist = q_dist[SIDX(sb + n - 1)];
-      tl_speed = q_speed[SIDX(sb + n - 1)];
+      const double2 tv = q_ds[SIDX(sb + n - 1)];
+      tl_dist = tv.x;
+      tl_speed = tv.y;
       tl_tag = S.tag[SIDX(sb + n - 1)];
     }
   } else {
@@ -1165,27 +1160,24 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     bool prefix = (s0 < k) && (m_self < 2 || s1 < k) && (m_self < 3 || s2 < k);
     if (prefix) {
       for (int i = k; i < n; i += 4) {
-        double nd[4], ns[4];
-        int tg[4], ax[4], bk[4];
+        double2 vv[4];
+        int2 mm[4];
+        int tg[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (i + u < n) {
-            nd[u] = q_dist[SIDX(sb + i + u)];
-            ns[u] = q_speed[SIDX(sb + i + u)];
+            vv[u] = q_ds[SIDX(sb + i + u)];
+            mm[u] = S.ab[SIDX(sb + i + u)];
             tg[u] = S.tag[SIDX(sb + i + u)];
-            ax[u] = S.aux[SIDX(sb + i + u)];
-            bk[u] = S.blk[SIDX(sb + i + u)];
           }
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (i + u < n) {
-            q_dist[SIDX(sb + i + u - k)] = nd[u];
-            q_speed[SIDX(sb + i + u - k)] = ns[u];
+            q_ds[SIDX(sb + i + u - k)] = vv[u];
+            S.ab[SIDX(sb + i + u - k)] = mm[u];
             S.tag[SIDX(sb + i + u - k)] = tg[u];
-            S.aux[SIDX(sb + i + u - k)] = ax[u];
-            S.blk[SIDX(sb + i + u - k)] = bk[u];
-            tl_dist = nd[u];
-            tl_speed = ns[u];
+            tl_dist = vv[u].x;
+            tl_speed = vv[u].y;
             tl_tag = tg[u];
           }
       }
@@ -1195,14 +1187,13 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     } else {
       for (int i = 0; i < n; i++) {
         if (i == s0 || i == s1 || i == s2) continue;
-        double nd = q_dist[SIDX(sb + i)], ns = q_speed[SIDX(sb + i)];
+        const double2 vi = q_ds[SIDX(sb + i)];
+        double nd = vi.x, ns = vi.y;
         int tg = S.tag[SIDX(sb + i)];
         if (w != i) {
-          q_dist[SIDX(sb + w)] = nd;
-          q_speed[SIDX(sb + w)] = ns;
+          q_ds[SIDX(sb + w)] = vi;
           S.tag[SIDX(sb + w)] = tg;
-          S.aux[SIDX(sb + w)] = S.aux[SIDX(sb + i)];
-          S.blk[SIDX(sb + w)] = S.blk[SIDX(sb + i)];
+          S.ab[SIDX(sb + w)] = S.ab[SIDX(sb + i)];
         }
         have_tail = true;
         tl_dist = nd;
@@ -1276,11 +1267,9 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         int pb = N.route_ptr[route], pe = N.route_ptr[route + 1];
         naux = (pb + seq + 1 < pe) ? N.route_drv[pb + seq + 1] : -1;
       }
-      q_dist[SIDX(sb + w)] = best_nd;
-      q_speed[SIDX(sb + w)] = ns;
+      q_ds[SIDX(sb + w)] = make_double2(best_nd, ns);
       S.tag[SIDX(sb + w)] = ntag;
-      S.aux[SIDX(sb + w)] = naux;
-      S.blk[SIDX(sb + w)] = S.obx_blk[best_ox];
+      S.ab[SIDX(sb + w)] = make_int2(naux, S.obx_blk[best_ox]);
       have_tail = true;
       tl_dist = best_nd;
       tl_speed = ns;
@@ -1300,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   int has_new = 0;
   if (spawn_possible) {
     int tail_tmpl = have_tail ? tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tl_tag)) : 0;
-    spawn_if_due<SINGLE>(N, S, q_dist, q_speed, r, d, sb, t_now + 1, w, have_tail, tl_dist, tail_tmpl, has_new);
+    spawn_if_due<SINGLE>(N, S, q_ds, r, d, sb, t_now + 1, w, have_tail, tl_dist, tail_tmpl, has_new);
   }
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
 }
@@ -1322,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_reset(DevNet N, DevState S, DevCfg C, c
   if (d < N.n_lanes) {
     S.spawn_cur[IDX(d)] = 0;
     S.fz[IDX(d)] = 0;
-    spawn_if_due<SINGLE>(N, S, S.dist, S.speed, r, d, N.drv_slot_base[d], 0, w, false, 0.0, 0, has_new);
+    spawn_if_due<SINGLE>(N, S, S.ds, r, d, N.drv_slot_base[d], 0, w, false, 0.0, 0, has_new);
   }
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
 }
@@ -1423,13 +1412,10 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   int q = 0;
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
-  double c_dist = n > 0 ? S.dist[SIDX(sb)] : 0.0, c_speed = n > 0 ? S.speed[SIDX(sb)] : 0.0;
+  double2 c_ds = n > 0 ? S.ds[SIDX(sb)] : make_double2(0.0, 0.0);
   for (int i = 0; i < n; i++) {
-    const double dist = c_dist, speed = c_speed;
-    if (i + 1 < n) { // next slot in flight while this one is binned
-      c_dist = S.dist[SIDX(sb + i + 1)];
-      c_speed = S.speed[SIDX(sb + i + 1)];
-    }
+    const double dist = c_ds.x, speed = c_ds.y;
+    if (i + 1 < n) c_ds = S.ds[SIDX(sb + i + 1)]; // next slot in flight while this one is binned
     if (speed < 0.1) q++;
     sum += speed;
     if (bins > 0) {
@@ -1489,12 +1475,13 @@ __global__ void k_posmat(DevNet N, DevState S, DevCfg C, double *posmat, int max
   if (bins <= 0) return;
   double bin_size = len / bins;
   for (int i = 0; i < n; i++) {
-    double pos = round6(S.dist[SIDX(sb + i)]);
+    const double2 vi = S.ds[SIDX(sb + i)];
+    double pos = round6(vi.x);
     if (pos < 0) pos = 0;
     else if (pos > len) pos = len;
     int idx = (int)py_floordiv(pos, bin_size);
     if (idx >= bins) idx = bins - 1;
-    double norm_speed = round6(S.speed[SIDX(sb + i)]) / maxspd;
+    double norm_speed = round6(vi.y) / maxspd;
     pm[idx] += 1.0;
     pm[idx] += norm_speed;
   }
@@ -1815,8 +1802,9 @@ __global__ void k_snapshot(DevNet N, DevState S, int rep, int cap, int *count, i
     if (k < cap) {
       drv[k] = d;
       slot[k] = i;
-      dist[k] = S.dist[SIDX(sb + i)];
-      speed[k] = S.speed[SIDX(sb + i)];
+      const double2 vi = S.ds[SIDX(sb + i)];
+      dist[k] = vi.x;
+      speed[k] = vi.y;
       vid[k] = TSC_TAG_VID(S.tag[SIDX(sb + i)]);
     }
   }
