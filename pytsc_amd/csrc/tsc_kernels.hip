@@ -387,7 +387,7 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 //                     on a side stream beside k_heavy.
 #define TSC_QCAP 512
 #define TSC_QMASK (TSC_QCAP - 1)
-#define TSC_EU 4    /* slots enumerated per turn in k_enum */
+#define TSC_EU 1    /* slots enumerated per turn in k_enum */
 #define TSC_MAXQ 4  /* out-links of a lane (checked at create): one H list per out-link */
 #define TSC_HCAP 512 /* items per global work list */
 #define TSC_NLIST (TSC_MAXQ + 1) /* work lists per (lane, replica block): one per out-link + plain followers */
@@ -708,7 +708,7 @@ __device__ __forceinline__ void wl_put(const DevState &S, int list, unsigned int
 
 // ------------------------------------------------------------------ k_enum
 template <bool SINGLE>
-__global__ __launch_bounds__(64, 4) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+__global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
   __shared__ unsigned int stage[TSC_NLIST][TSC_STAGE];
   int rb, row;
   if (!map_block(n_rb, n_rows, rb, row)) return;
