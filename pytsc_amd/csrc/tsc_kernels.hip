@@ -1375,8 +1375,18 @@ __device__ __forceinline__ double round6(double x) {
   else if (rr < -0.5) k -= 1.0;
   return k / 1e6;
 }
-// CPython float floor division a // b for b > 0
+// CPython float floor division a // b for a >= 0, b > 0.  CPython derives it from the exact
+// fmod and repairs the rounding of (a - mod) / b, so the result is the mathematical
+// floor(a / b); when the remainder of the rounded quotient is clear of both bin edges
+// (by 1e-9 b, far above the rounding of one fma) that quotient's floor is the same
+// number, and the fmod loop is only run for values sitting on an edge.
 __device__ __forceinline__ double py_floordiv(double a, double b) {
+  {
+    const double k = floor(a / b);
+    const double rem = fma(-k, b, a);
+    const double tol = 1e-9 * b;
+    if (a >= 0.0 && rem > tol && rem < b - tol) return k;
+  }
   double mod = fmod(a, b);
   double div = (a - mod) / b;
   if (mod != 0.0 && (mod < 0.0)) div -= 1.0;
@@ -1387,17 +1397,19 @@ __device__ __forceinline__ double py_floordiv(double a, double b) {
 
 #define MEASURE_WAVES 4
 #define MAX_VIS 16
-// Lane measurements (reference retriever.py:54-85, :20-52): counts, queue,
-// speed sum in list order, and the two visibility windows of the position
-// matrix binned in LDS (one private column per thread).
+// Lane measurements (reference retriever.py:54-85, :20-52): counts, queue, speed sum in
+// list order, and the two visibility windows of the position matrix.  A bin of the
+// matrix holds x = -1 + sum over its vehicles of (1 + speed / max speed), added in list
+// order; what the observation needs of it are three predicates -- x >= 0, x == 0.0,
+// x >= 1.0 -- and with every term non-negative those follow from the number of vehicles
+// in the bin (0, 1, more) and, for a single vehicle, from its own term (x is then exactly
+// that term: (-1 + 1) + s): kept as bit masks in registers, one bit per window bin.
 __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevState S, DevCfg C, int n_rb, int n_lblk) {
-  __shared__ double win[2 * MAX_VIS][MEASURE_WAVES][64];
   int rb, lblk;
   if (!map_block(n_rb, n_lblk, rb, lblk)) return;
   int l = __builtin_amdgcn_readfirstlane(lblk * (int)blockDim.y + (int)threadIdx.y);
   int r = rb * 64 + threadIdx.x;
   if (l >= N.n_lanes || r >= S.R) return;
-  const int wy = threadIdx.y, lx = threadIdx.x;
   const int vis = C.visibility;
   int hdr = S.cnt[IDX(l)];
   int n = (hdr & TSC_CNT_MASK) - ((hdr & TSC_NEW_BIT) ? 1 : 0);
@@ -1408,53 +1420,55 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   // padded matrix length and the two windows [-vis:] and [:vis]
   const int plen = bins < vis ? vis : bins;
   const int in0 = plen - vis;
-  for (int b = 0; b < 2 * vis; b++) win[b][wy][lx] = -1.0;
+  unsigned int in_one = 0, in_two = 0, in_zero = 0, in_ge1 = 0, out_one = 0;
   int q = 0;
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
-  double2 c_ds = n > 0 ? S.ds[SIDX(sb)] : make_double2(0.0, 0.0);
-  for (int i = 0; i < n; i++) {
-    const double dist = c_ds.x, speed = c_ds.y;
-    if (i + 1 < n) c_ds = S.ds[SIDX(sb + i + 1)]; // next slot in flight while this one is binned
-    if (speed < 0.1) q++;
-    sum += speed;
-    if (bins > 0) {
+  for (int i0 = 0; __builtin_amdgcn_ballot_w64(i0 < n); i0 += 4) {
+    double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i0 + u < n) v[u] = S.ds[SIDX(sb + i0 + u)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i0 + u >= n) continue;
+      const double dist = v[u].x, speed = v[u].y;
+      if (speed < 0.1) q++;
+      sum += speed;
+      if (bins <= 0) continue;
       double pos = round6(dist);
       if (pos < 0) pos = 0;
       else if (pos > len) pos = len;
       int idx = (int)py_floordiv(pos, bin_size);
       if (idx >= bins) idx = bins - 1;
-      double norm_speed = round6(speed) / maxspd;
+      if (idx < vis) out_one |= 1u << idx;
       if (idx >= in0) {
-        double x = win[idx - in0][wy][lx];
-        x += 1.0;
-        x += norm_speed;
-        win[idx - in0][wy][lx] = x;
-      }
-      if (idx < vis) {
-        double x = win[vis + idx][wy][lx];
-        x += 1.0;
-        x += norm_speed;
-        win[vis + idx][wy][lx] = x;
+        const unsigned int bit = 1u << (idx - in0);
+        if (in_one & bit) {
+          in_two |= bit;
+        } else {
+          in_one |= bit;
+          const double norm_speed = speed == 0.0 ? 0.0 : round6(speed) / maxspd;
+          if (norm_speed == 0.0) in_zero |= bit;
+          if (norm_speed >= 1.0) in_ge1 |= bit;
+        }
       }
     }
   }
   // 3 predicate bits per incoming-window bin: occupied (>= 0), zero (== 0), >= 1
-  unsigned int ib = 0, obits = 0;
+  unsigned int ib = 0;
   for (int b = 0; b < vis; b++) {
-    double x = win[b][wy][lx];
-    if (x >= 0.0) ib |= 1u << (3 * b);
-    if (x == 0.0) ib |= 2u << (3 * b);
-    if (x >= 1.0) ib |= 4u << (3 * b);
-    double y = win[vis + b][wy][lx];
-    if (y >= 0.0) obits |= 1u << b;
+    const unsigned int one = (in_one >> b) & 1u, two = (in_two >> b) & 1u;
+    if (one) ib |= 1u << (3 * b);
+    if (one && !two && ((in_zero >> b) & 1u)) ib |= 2u << (3 * b);
+    if (two || (one && ((in_ge1 >> b) & 1u))) ib |= 4u << (3 * b);
   }
   S.lane_n[IDX(l)] = n;
   S.lane_q[IDX(l)] = q;
   if (q) atomicAdd(&S.nq_all[r], q);
   S.lane_sum[IDX(l)] = sum;
   S.lane_in_bits[IDX(l)] = ib;
-  S.lane_out_bits[IDX(l)] = obits;
+  S.lane_out_bits[IDX(l)] = out_one;
 }
 
 // Full position matrices for the single-replica facade / parity checks.

@@ -6,11 +6,12 @@ import torch
 from bench import workload_tables
 from pytsc_amd.vec_env import VecEngine
 
-tables = workload_tables(4, 4, 4096, 0, 700.0, 8)
+R = int(os.environ.get('TSC_R', '4096'))
+tables = workload_tables(4, 4, R, 0, 700.0, 8)
 eng = VecEngine(tables, want=("mask",))
 buf = eng.observe()
 g = torch.Generator(device="cuda"); g.manual_seed(0)
-u = torch.empty((4096, 16, 16), device="cuda")
+u = torch.empty((R, 16, 16), device="cuda")
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 150):
     u.uniform_(1e-6, 1.0, generator=g)
     buf = eng.step((u * buf["mask"]).argmax(-1).to(torch.int32))
