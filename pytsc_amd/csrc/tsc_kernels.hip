@@ -102,9 +102,13 @@ __device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, do
   s = min2(s, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) / (t.headway + interval / 2));
   return s;
 }
-__device__ __forceinline__ double stop_before_speed(double speed, const Tm &t, double distance, double interval) {
+// distance covered by one more acceleration step followed by usual braking to a stop
+__device__ __forceinline__ double brake_distance_after_accel(double speed, const Tm &t, double interval) {
   double nextSpeed = speed + t.maxPosAcc * interval;
-  double bd = (speed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / t.usualNegAcc / 2);
+  return (speed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / t.usualNegAcc / 2);
+}
+__device__ __forceinline__ double stop_before_speed(double speed, const Tm &t, double distance, double interval) {
+  double bd = brake_distance_after_accel(speed, t, interval);
   if (bd < distance) return speed + t.maxPosAcc * interval;
   double takeInterval = 2 * distance / (speed + 1e-9) / interval;
   if (takeInterval >= 1) {
@@ -743,6 +747,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
 #pragma unroll
   for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
   const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
+  const double bd0 = brake_distance_after_accel(0.0, load_tm(N, 0), C.interval);
   // which out-links are green in this replica (bit q): a head stopped at a red light is settled here
   int green_bits = 0xf;
   if (qb < qe && own_valid) {
@@ -870,11 +875,11 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
           // one more acceleration step: the stop-line bound of getNextSpeed is 0 (its
           // link is not available and it can brake), no cross is scanned (so no blocker),
           // every other bound is clamped by it: v = 0 and the position is unchanged.
-          const Tm t = load_tm(N, tid);
+          // (stop_before_speed(0, rest) is 0 exactly when one more acceleration step could
+          // not be braked off within `rest` > 0; at rest == 0 it is 0/0, left to k_exec.)
           const double rest = L - dist;
-          if (rest <= t.approach && !(min_brake_distance(speed, t) > rest) &&
-              stop_before_speed(speed, t, rest, C.interval) == 0.0)
-            settled = true;
+          const double bd = SINGLE ? bd0 : brake_distance_after_accel(0.0, load_tm(N, tid), C.interval);
+          if (rest <= approach && rest > 0.0 && !(bd < rest)) settled = true;
         }
         if (is > 0 && speed == 0 && p_speed == 0) {
           // A lane vehicle stopped behind a stopped leader within minGap: both
