@@ -130,7 +130,7 @@ def main():
             reset_finished(buf)
     torch.cuda.synchronize(dev)
     v0 = eng.mean_vehicles()
-    eng.profile(True)
+    eng.profile(4)  # HIP-event bracket around k_exec on every 4th sub-step (rotates over the 5 positions)
     sharding.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -152,7 +152,7 @@ def main():
 
     if rank == 0:
         # roofline of the dominant kernel: algorithmic bytes per
-        # agent-env-step B = 48*V_a + 1356; one k_drive launch
+        # agent-env-step B = 48*V_a + 1356; one k_exec launch
         # advances R*A agents by one of the delta_time sub-steps = R*A/5 units.
         va = 0.5 * (v0 + v1) / A
         bytes_per_unit = 48.0 * va + 1356.0
@@ -175,7 +175,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                "kernel": "k_drive (lane grid; the lane-link grid runs beside it on a side stream)",
+                "kernel": "k_exec (dense 64-item batches of lane / lane-link work items)",
                 "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
                 "bytes_per_agent_env_step": bytes_per_unit, "V_a": va,
                 "note": "latency/occupancy-bound f64 scalar work, not HBM-bound (DESIGN.md §5)",

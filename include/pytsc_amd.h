@@ -281,10 +281,11 @@ int tsc_errors(tsc_handle_t h, int32_t *n_errors);
 int tsc_mean_vehicles(tsc_handle_t h, double *mean);
 
 /* Kernel timing with HIP events on the stream the kernels are launched on:
- * while enabled, every launch of the dominant kernel (k_action, one per engine
- * sub-step) is bracketed by an event pair.  tsc_profile_read synchronises,
- * returns the summed duration [ms] and the number of launches since enable, and
- * clears the accumulators. */
+ * while enabled (on = n > 0), the launch of the dominant kernel (k_exec, one per
+ * engine sub-step) is bracketed by an event pair on every n-th sub-step (an event
+ * record costs a few microseconds of pipeline bubble; n = 1 brackets them all).
+ * tsc_profile_read synchronises, returns the summed duration [ms] and the number
+ * of bracketed launches since enable, and clears the accumulators. */
 int tsc_profile_enable(tsc_handle_t h, int on);
 int tsc_profile_read(tsc_handle_t h, double *total_ms, int32_t *n_launches);
 

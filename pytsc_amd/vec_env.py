@@ -136,7 +136,7 @@ class VecEngine:
         return m.value
 
     def profile(self, on):
-        _lib.check(self.lib.tsc_profile_enable(self.h, 1 if on else 0), "tsc_profile_enable")
+        _lib.check(self.lib.tsc_profile_enable(self.h, int(on)), "tsc_profile_enable")
 
     def profile_read(self):
         ms, n = C.c_double(0), C.c_int32(0)
