@@ -12,7 +12,7 @@ replicas per GPU); torch.distributed is used only for the barrier around the
 timed region and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line (rank 0) with the throughput, the roofline object of the
-dominant kernel (k_drive, timed live with HIP events on its stream) and the CPU
+dominant kernel (k_exec, timed live with HIP events on its stream) and the CPU
 baseline (the scalar oracle on one host core, bounded sample).
 """
 import argparse
@@ -159,6 +159,15 @@ def main():
         units_per_launch = R * A / 5.0
         avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
         achieved = bytes_per_unit * units_per_launch / avg_launch_s / 1e9 if k_n else None
+        # HBM-side bytes per k_exec launch from the committed PMC passes (profiles/, separate
+        # rocprofv3 runs: counters cannot be read inside this process), at this run's duration
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        if k_n and os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj["bytes_per_launch"] / avg_launch_s / 1e9
+            traffic_src = "profiles/r01_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) per k_exec launch"
         line = {
             "metric": "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X",
             "value": value, "unit": "agent-env-steps/s", "n_gpus": world_size, "steps": args.steps,
@@ -174,11 +183,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "k_exec (dense 64-item batches of lane / lane-link work items)",
                 "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
                 "bytes_per_agent_env_step": bytes_per_unit, "V_a": va,
-                "note": "latency/occupancy-bound f64 scalar work, not HBM-bound (DESIGN.md §5)",
+                "note": "memory-side traffic is several times the algorithmic bytes (scattered 16-byte records cost 64-byte requests); "
+                        "the kernel is latency/occupancy-limited at 4 waves per SIMD, not bandwidth-limited (DESIGN.md §5)",
             },
         }
         if not args.no_cpu_baseline:

@@ -89,7 +89,7 @@ struct DevState {
   int *obx_slot, *obx_tag, *obx_aux, *obx_blk;
   double *obx_dist, *obx_speed;
   double *tail_dist, *tail_speed;   // tail record of the committed state (the tail before a spawn)
-  double *ntail_dist, *ntail_speed; // next half: written by k_drive (quiet drivables) / k_commit, then swapped in
+  double *ntail_dist, *ntail_speed; // next half: written by k_enum / k_exec (quiet drivables) / k_commit, then swapped in
   // per lane [n_lanes * RS]
   int *spawn_cur, *lane_n, *lane_q;
   int *fz; // [lane][replica] k_enum's standing block: fa | fb << 16 (slots (fa, fb] are skipped)
@@ -105,21 +105,20 @@ struct DevState {
   unsigned long long *fin_dsum, *fin_ssum; // sums over finished vehicles: duration, creation step
   // per vid [max_veh * RS]: committed blocker of a running vehicle, ping-pong halves
   int *bbv, *nbbv;
-  // work lists of k_enum for k_exec (all replicas): wl_nb[2] batch counts (lanes, links)
+  // work lists of k_enum for k_exec (all replicas): wl_nb[0] = number of batches (wl_nb[1] unused)
   // followed in the same allocation by wl_cnt[n_lists]; both zeroed before every k_enum.
   int *wl_nb;
   int n_lists;
   int *wl_cnt;
   const ListRec *wl_rec;   // [n_lists]
   unsigned int *wl_items;
-  int2 *wl_desc;           // batch table: lanes from 0, lane-links from wl_desc_link0
-  long long wl_desc_link0;
+  int2 *wl_desc;           // batch table of k_plan: (list, batch)
   int *errors; // [4]: slot overflow, outbox overflow, bad action, other
 };
 
 struct DevCfg {
   int delta_time, yellow_time, action_space, round_robin, visibility, sim_length, episode_limit;
   int initial_wait_time, set_offset, sequential_sets, reward_kind, n_actions, obs_size, state_size;
-  int ablate; // diagnostic builds only (TSC_ABLATE env): skip parts of k_action to price them; 0 in every real run
+  int ablate; // diagnostic builds only (TSC_ABLATE env): skip parts of k_enum / k_exec to price them; 0 in every real run
   double interval, veh_size_min_gap, flickering_coef;
 };

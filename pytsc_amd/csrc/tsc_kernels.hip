@@ -1,16 +1,20 @@
 // Hand-written HIP kernels (gfx950 / CDNA4) of the batched traffic microsimulator:
 // the hot path TrafficSignalNetwork.step() (reference pytsc/__init__.py:178-182).
 //
-// Decomposition: lane-of-wave <-> env replica; a wavefront is 64
-// consecutive replicas of ONE drivable (lane or lane-link) or ONE agent, so HBM
-// accesses coalesce along the replica axis and topology is wave-uniform
-// (scalar loads, no divergence on the network structure).  One engine sub-step
-// is three launches (Jacobi update: decisions read the committed state):
-//   k_notify  (agent   x replica)  cross occupancy masks per intersection
-//   k_action  (drivable x replica) leader/gap, car-following, signal gating,
-//                                  cross yielding -> buffered speed/position
-//   k_commit  (drivable x replica) compaction, hand-off pull from feeder
-//                                  drivables, retire, spawn for the next step
+// Decomposition: kernels that walk state in order put 64 consecutive
+// replicas of ONE drivable (lane or lane-link) or ONE agent on the lanes of a wavefront,
+// so HBM accesses coalesce along the replica axis and topology is wave-uniform (scalar
+// loads, no divergence on the network structure); the arithmetic runs on dense batches
+// of 64 work items drawn from all replicas.  One engine sub-step is five launches
+// (Jacobi update: decisions read the committed state):
+//   k_notify  (agent    x replica)  cross occupancy masks per intersection
+//   k_enum    (drivable x replica)  classification: settled vehicles are finished here,
+//                                   the others go to work lists spanning all replicas
+//   k_plan    (list)                list counts -> batch table
+//   k_exec    (batch of 64 items)   leader/gap, car-following, signal gating, cross
+//                                   yielding -> buffered speed/position, outbox
+//   k_commit  (drivable x replica)  compaction, hand-off pull from feeder drivables,
+//                                   retire, spawn for the next step
 // and one env step ends with k_measure (lane x replica), k_agent (agent x
 // replica, observations staged through LDS for coalesced [R, A, obs] stores)
 // and k_stats (replica).  No MFMA: this is integer / f64 scalar work.
@@ -262,7 +266,7 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
   return f;
 }
 
-// ---------------------------------------------------------------- k_action
+// ------------------------------------------------- car-following / cross helpers of k_exec
 // Cross::canPass
 __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &S, int r, double speed, const Tm &t,
                                                int vid, int ell, int t1, int t2, double d1, const Foe &f,
@@ -330,7 +334,6 @@ __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &
 // half of blocker_by_vid is refreshed once more after a blocker disappears).
 #define TSC_BLK_VID(w) ((int)((w) & 0xffffff) - 1)
 #define TSC_BLK_OLDER(w) (((w) >> 30) & 1)
-#define TSC_HSCAN 12 /* slots of a lane scanned by k_action for vehicles near the lane end */
 
 // Resolve the cross conflicts of one vehicle on / approaching lane-link `link`
 // (wave-uniform): first cross ahead, in distance order, that it may not pass.
@@ -365,43 +368,31 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
   }
 }
 
-// ------------------------------------------------------------------ k_drive
-// The engine sub-step's decision stage, three kernels with the same two roles:
-//  (1) enumeration: one wavefront = 64 replicas of ONE drivable; lane l walks the
-//      slots of ITS replica (coalesced loads along the replica axis, wave-uniform
-//      topology, software-pipelined) and classifies every vehicle:
-//        - lane vehicle stopped in a stopped queue -> result known without
-//          arithmetic (v = 0, position unchanged), stored at once;
-//        - plain follower (not the head, not within the approach distance of the
-//          lane end)                                  -> work queue F;
-//        - head / near the lane end / on a lane-link -> work queue H of its next
-//          lane-link;
-//  (2) execution: 64 work items at a time, one per lane -- whatever replica and slot
-//      they came from -- run the car-following / intersection logic with all lanes
-//      busy and the loads of a batch issued as one group.
-// Replicas hold very different numbers of vehicles, so walking slots in lock-step
+// --------------------------------------------------------- decision stage: k_enum / k_exec
+// (1) k_enum -- enumeration: one wavefront = 64 replicas of ONE drivable; lane l walks the
+//     slots of ITS replica (coalesced loads along the replica axis, wave-uniform topology,
+//     next row in flight) and classifies every vehicle:
+//       - lane vehicle stopped in a stopped queue, lane head standing at a red light
+//         -> result known without arithmetic (v = 0, position unchanged), stored at once;
+//       - plain follower (not the head, not within the approach distance of the lane
+//         end)                                    -> the lane's follower list;
+//       - head / near the lane end / on a lane-link -> the list of its next lane-link;
+// (2) k_exec -- execution: 64 work items at a time, one per lane -- whatever replica and
+//     slot they came from -- run the car-following / intersection logic with all lanes busy.
+// Replicas hold very different numbers of moving vehicles, so walking slots in lock-step
 // leaves most lanes idle (23 % of VALU lanes active in the v1 kernel); the engine's
 // update is Jacobi (every decision reads only committed state), so vehicles can be
-// executed in any grouping.  Items of a batch come from neighbouring replicas of
-// the same drivable: their global accesses stay within the same few 512-byte rows.
-//   k_enum   (lanes): enumeration + follower batches; H queues go to global lists.
-//                     Small register footprint -> 8 waves per SIMD.
-//   k_heavy  (lanes): one wavefront per (lane, 64 replicas, out-link) executes that list.
-//   k_drive_link    : enumeration + execution for lane-links (few vehicles each), run
-//                     on a side stream beside k_heavy.
-#define TSC_QCAP 512
-#define TSC_QMASK (TSC_QCAP - 1)
+// executed in any grouping.
 #define TSC_EU 1    /* slots enumerated per turn in k_enum */
-#define TSC_MAXQ 4  /* out-links of a lane (checked at create): one H list per out-link */
-#define TSC_HCAP 512 /* items per global work list */
-#define TSC_NLIST (TSC_MAXQ + 1) /* work lists per (lane, replica block): one per out-link + plain followers */
+#define TSC_MAXQ 4  /* out-links of a lane (checked at create): one work list per out-link */
+#define TSC_NLIST (TSC_MAXQ + 1) /* work lists per lane: one per out-link + plain followers */
 // work item: (replica << 10) | (slot << 1) | is-tail
 #define TSC_ITEM(rep, slot, tail) ((unsigned int)(((unsigned int)(rep) << 10) | ((slot) << 1) | ((tail) ? 1u : 0u)))
 #define TSC_ITEM_TAIL(m) ((m) & 1u)
 #define TSC_ITEM_REP(m) ((int)((m) >> 10))
 #define TSC_ITEM_SLOT(m) ((int)(((m) >> 1) & 511u))
 
-// ---- a plain follower (item: replica rl of the block, slot it >= 1)
+// ---- a plain follower (item: replica r, slot it >= 1)
 template <bool SINGLE>
 __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, const ListRec &lr, double interval,
                                             bool valid, int r, int it, bool is_tail, int ablate = 0) {
@@ -1050,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   const bool is_link = d >= N.n_lanes;
   const int sb = N.drv_slot_base[d];
   const int cap = N.drv_cap[d];
-  // the half k_action just wrote: it becomes the committed state after this kernel
+  // the half k_enum / k_exec just wrote: it becomes the committed state after this kernel
   double2 *__restrict__ q_ds = S.nds;
   // ---- everything the quiet test needs is loaded up front, in one round trip
   int fb, fe;
