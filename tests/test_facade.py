@@ -170,3 +170,44 @@ def test_wrappers_keep_the_smac_api():
     r, d, i = env2.step(acts)
     assert r == pytest.approx(exp["global_reward"][0])
     env2.close()
+
+
+def test_domain_randomized_wrapper_pads_to_the_largest_map():
+    """pytsc/wrappers/epymarl.py:112-336: fixed interface over maps of different
+    size; a new map is drawn when the simulated hour is over."""
+    import random
+
+    from pytsc_amd.flows import poisson_flows
+    from pytsc_amd.grid import generate_grid
+    from pytsc_amd.roadnet import RoadNet
+    from pytsc_amd.wrappers.epymarl import DomainRandomizedEPyMARLTrafficSignalNetwork
+
+    maps = {}
+    for name, (r, c) in {"syn_1x2": (1, 2), "syn_2x2": (2, 2)}.items():
+        net = generate_grid(r, c)
+        maps[name] = {"hip": {"roadnet_json": net,
+                              "flow_entries": [poisson_flows(RoadNet(net), 500.0, horizon=200, seed=1)],
+                              "sim_length": 60, "episode_limit": 4}}
+    env = DomainRandomizedEPyMARLTrafficSignalNetwork(
+        list(maps), "hip", map_kwargs=maps, rng=random.Random(5), engine_factory=oracle_engine_factory,
+        signal={"action_space": "phase_selection", "round_robin": False})
+    assert env.max_n_agents == 4
+    seen = set()
+    for episode in range(12):
+        n_before = env.current_n_agents  # reset() reads obs/state BEFORE it may draw a new map (as the reference)
+        obs, state = env.reset()
+        seen.add(env.current_map)
+        n = env.current_n_agents
+        info = env.get_env_info()
+        assert info["n_agents"] == 4 and np.asarray(info["adjacency_matrix"]).shape == (4, 4)
+        assert np.asarray(obs).shape == (4, env.get_obs_size()) and np.asarray(state).shape == (4, env.get_state_size())
+        assert all(row == [-1] * env.get_obs_size() for row in obs[n_before:])
+        for _ in range(4):
+            mask = env.get_avail_actions()
+            assert len(mask) == 4 and all(row == [1] * env.get_total_actions() for row in mask[n:])
+            acts = [int(np.argmax(row)) for row in mask]  # 4 actions, the surplus ones are ignored
+            obs, reward, done, truncated, _ = env.step(acts)
+            assert len(obs) == 4 and len(env.get_local_rewards()) == 4 and env.get_local_rewards()[n:] == [0] * (4 - n)
+        assert done
+    assert seen == set(maps)  # both maps were drawn
+    env.close()
