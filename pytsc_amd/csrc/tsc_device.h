@@ -66,6 +66,7 @@ struct DevNet {
   const int *agent_nbr_ptr, *agent_nbr;
   const double *agent_nbr_w;
   const int *route_ptr, *route_drv;
+  const int2 *veh_rrange; // per vehicle (all flow sets): [begin, end) of its route in route_drv
   const double *tmpl;
   // flows
   int n_sets, sim_len;

@@ -1019,8 +1019,8 @@ __device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S,
     atomicAdd(&S.errors[0], 1);
     return;
   }
-  int route = N.veh_route[vbase + vid];
-  int rb_ = N.route_ptr[route], re_ = N.route_ptr[route + 1];
+  const int2 rr_ = N.veh_rrange[vbase + vid];
+  int rb_ = rr_.x, re_ = rr_.y;
   q_ds[SIDX(sb + w)] = make_double2(0.0, 0.0);
   S.tag[SIDX(sb + w)] = TSC_MAKE_TAG(vid, 0);
   S.ab[SIDX(sb + w)] = make_int2((rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1, 0);
@@ -1054,6 +1054,8 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   const int hdr = S.cnt[IDX(d)];
   const int o_raw = S.ob[IDX(d)];
+  const int set_r = S.set[r];
+  const int t_now = S.t[r];
   int o_feed[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < 4; q++)
@@ -1097,10 +1099,9 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     }
   }
   const bool arrivals = n_arr > 0;
-  const int t_now = S.t[r];
   bool spawn_possible = false;
   if (!is_link && N.lane_is_entry[d]) {
-    int set = S.set[r];
+    int set = set_r;
     int qb = N.spawn_ptr[set * N.n_lanes + d], qe = N.spawn_ptr[set * N.n_lanes + d + 1];
     if (qb != qe) {
       int c = S.spawn_cur[IDX(d)];
@@ -1117,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     }
     return;
   }
-  const int vbase = N.set_veh_ptr[S.set[r]];
+  const int vbase = N.set_veh_ptr[set_r];
   int tp = (hdr & TSC_NEW_BIT) ? -1 : S.tail_prev[IDX(d)];
   // ---- keep / retire
   const size_t oxs = (size_t)d * TSC_OB_MAX * (size_t)S.RS + (size_t)r;
@@ -1205,8 +1206,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     // the previous tail left while others stayed (overlap corner case): recover
     // the new tail's previous drivable from its route
     int vid = TSC_TAG_VID(tl_tag), seq = TSC_TAG_SEQ(tl_tag);
-    int route = N.veh_route[vbase + vid];
-    tp = seq > 0 ? N.route_drv[N.route_ptr[route] + seq - 1] : -1;
+    tp = seq > 0 ? N.route_drv[N.veh_rrange[vbase + vid].x + seq - 1] : -1;
   }
   // ---- pull newcomers from feeder outboxes, in descending buffered distance
   if (arrivals) {
@@ -1216,13 +1216,20 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       double best_nd = -1e300;
       int best_vid = 0x7fffffff, best_f = -1;
       size_t best_ox = 0;
+      int tg = 0, nblk = 0;
+      double ns = 0;
+      bool have_rec = false;
       if (n_arr == 1) {
-        // the usual case, one arrival: no ordering needed
+        // the usual case, one arrival: no ordering needed, the whole record in one round trip
         if (pass > 0) break;
         best_f = first_f;
         best_ox = ((size_t)first_f * TSC_OB_MAX + first_k) * (size_t)S.RS + (size_t)r;
         best_nd = S.obx_dist[best_ox];
-        best_vid = TSC_TAG_VID(S.obx_tag[best_ox]);
+        tg = S.obx_tag[best_ox];
+        ns = S.obx_speed[best_ox];
+        nblk = S.obx_blk[best_ox];
+        best_vid = TSC_TAG_VID(tg);
+        have_rec = true;
       } else
       for (int q = fb; q < fe; q++) {
         int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
@@ -1251,21 +1258,23 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         atomicAdd(&S.errors[0], 1);
         break;
       }
-      int tg = S.obx_tag[best_ox];
+      if (!have_rec) {
+        tg = S.obx_tag[best_ox];
+        ns = S.obx_speed[best_ox];
+        nblk = S.obx_blk[best_ox];
+      }
       int seq = TSC_TAG_SEQ(tg) + 1;
-      double ns = S.obx_speed[best_ox];
       int ntag = TSC_MAKE_TAG(best_vid, seq);
       int naux;
       if (is_link) {
         naux = t_now; // enterLaneLinkTime
       } else {
-        int route = N.veh_route[vbase + best_vid];
-        int pb = N.route_ptr[route], pe = N.route_ptr[route + 1];
-        naux = (pb + seq + 1 < pe) ? N.route_drv[pb + seq + 1] : -1;
+        const int2 rr = N.veh_rrange[vbase + best_vid]; // the vehicle's slice of route_drv
+        naux = (rr.x + seq + 1 < rr.y) ? N.route_drv[rr.x + seq + 1] : -1;
       }
       q_ds[SIDX(sb + w)] = make_double2(best_nd, ns);
       S.tag[SIDX(sb + w)] = ntag;
-      S.ab[SIDX(sb + w)] = make_int2(naux, S.obx_blk[best_ox]);
+      S.ab[SIDX(sb + w)] = make_int2(naux, nblk);
       have_tail = true;
       tl_dist = best_nd;
       tl_speed = ns;
