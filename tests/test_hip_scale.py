@@ -143,3 +143,61 @@ def test_congested_queues_match_oracle(oracle_lib):
     assert eng.mean_vehicles() > 150  # the network did fill up
     assert eng.errors() == 0 and orc.errors() == 0
     eng.close()
+
+
+def test_mixed_vehicle_templates_match_oracle(oracle_lib):
+    """Three vehicle templates (car, van, slow truck) in one demand: the multi-template
+    instantiations of k_enum / k_exec / k_commit (per-vehicle parameter look-ups, leader
+    lengths in gaps, approach distances) under congestion, against the oracle."""
+    import torch
+
+    from pytsc_amd.config import Config
+    from pytsc_amd.flows import DEFAULT_VEHICLE, poisson_flows
+    from pytsc_amd.grid import generate_grid
+    from pytsc_amd.roadnet import RoadNet
+    from pytsc_amd.scenario import build_tables
+    from pytsc_amd.vec_env import VecEngine
+
+    net = generate_grid(2, 3)
+    rn = RoadNet(net)
+    van = dict(DEFAULT_VEHICLE, length=7.0, maxPosAcc=1.5, usualPosAcc=1.5, maxSpeed=9.5, minGap=3.0)
+    truck = dict(DEFAULT_VEHICLE, length=12.0, maxPosAcc=1.0, usualPosAcc=1.0, maxNegAcc=3.5, usualNegAcc=3.0,
+                 maxSpeed=7.5, minGap=3.5, headwayTime=2.0)
+    sets = []
+    for seed in (0, 1):
+        entries = poisson_flows(rn, 1300.0, horizon=700, seed=seed)
+        rng = np.random.default_rng(100 + seed)
+        for e in entries:
+            k = rng.integers(0, 10)
+            e["vehicle"] = truck if k == 0 else (van if k < 4 else dict(DEFAULT_VEHICLE))
+        sets.append(entries)
+
+    def tables(R):
+        cfg = Config("syn_2x3", signal={"action_space": "phase_selection", "round_robin": False},
+                     hip={"roadnet_json": net, "flow_entries": sets, "sim_length": 700})
+        return build_tables(cfg, n_replicas=R)
+
+    R = 4
+    eng = VecEngine(tables(R))
+    orc = oracle_lib.Oracle(tables(R))
+    rng = np.random.default_rng(5)
+    out = orc.observe()
+    hold = np.zeros((R, 6), dtype=np.int32)
+    for s in range(120):
+        m = out.mask
+        pick = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        for r in range(R):
+            if s % (2 + 4 * r) == 0:
+                hold[r] = pick[r]
+        acts = np.where(np.take_along_axis(m, hold[..., None], -1)[..., 0] > 0, hold, pick).astype(np.int32)
+        out = orc.step(acts)
+        buf = eng.step(torch.tensor(acts, device="cuda"))
+        assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+        assert np.array_equal(buf["stats"].cpu().numpy(), out.stats), s
+        if s % 10 == 9:
+            for r in range(R):
+                a, b = orc.snapshot(r), eng.snapshot(r)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (s, r)
+    assert eng.mean_vehicles() > 100
+    assert eng.errors() == 0 and orc.errors() == 0
+    eng.close()
