@@ -739,6 +739,14 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
   const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
   const double bd0 = brake_distance_after_accel(0.0, load_tm(N, 0), C.interval);
+  // is any vehicle on a lane-link leaving this lane?  (look-ahead of a free-running head; loaded
+  // with the first slots, not after them)
+  bool out_links_empty = true;
+  if (own_valid && n > 0) {
+#pragma unroll
+    for (int qq = 0; qq < TSC_MAXQ; qq++)
+      if (olk[qq] >= 0 && (S.cnt[IDX(olk[qq])] & TSC_CNT_MASK) > 0) out_links_empty = false;
+  }
   // which out-links are green in this replica (bit q): a head stopped at a red light is settled here
   int green_bits = 0xf;
   if (qb < qe && own_valid) {
@@ -882,18 +890,44 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
           const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
           if (p_dist - plen - dist <= mg) settled = true;
         }
-        if (settled) {
+        double out_d = dist, out_v = 0.0;
+        bool finished = settled;
+        if (u == 0 && is == 0 && !settled && !(C.ablate & 8192)) {
+          // A lane head farther from the lane end than the look-ahead limit, with no vehicle
+          // on any lane-link leaving the lane (or leaving the network at the lane end): no
+          // leader within reach, not yet concerned by the signal or the crosses -- free
+          // acceleration, three comparisons.  It cannot reach the lane end in this step.
+          const Tm t = load_tm(N, tid);
+          const double rest = L - dist;
+          const double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * C.interval * 2;
+          if (rest > limit && rest > t.approach && rest > 2 * t.maxSpeed * C.interval) {
+            const bool clear = aux2[u] < 0 || out_links_empty;
+            if (clear) {
+              double v = t.maxSpeed;
+              v = min2(v, speed + t.maxPosAcc * C.interval);
+              v = min2(v, N.drv_max_speed[d]);
+              v = min2(v, t.maxSpeed);
+              v = max2(v, speed - t.maxNegAcc * C.interval);
+              if (!(v < 0)) {
+                out_v = v;
+                out_d = (speed + v) * C.interval / 2 + dist;
+                finished = true;
+              }
+            }
+          }
+        }
+        if (finished) {
           bucket = -1;
           if (blkw != 0) { // let an earlier blocker entry expire
             S.ab[SIDX(sb + is)].y = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
             S.nbbv[IDX(TSC_TAG_VID(S.tag[SIDX(sb + is)]))] = -1;
           }
           if (!(C.ablate & 512)) {
-            o_ds[SIDX(sb + is)] = make_double2(dist, 0.0);
+            o_ds[SIDX(sb + is)] = make_double2(out_d, out_v);
           }
           if (is == n - 1) {
-            S.ntail_dist[IDX(d)] = dist;
-            S.ntail_speed[IDX(d)] = 0.0;
+            S.ntail_dist[IDX(d)] = out_d;
+            S.ntail_speed[IDX(d)] = out_v;
           }
         }
         if (!run_final) {
