@@ -23,11 +23,12 @@
 // (compiled with -ffp-contract=off on both sides) so results are bit-identical.
 #include "tsc_device.h"
 
-#define IDX(row) ((size_t)(row) * (size_t)S.RS + (size_t)r)
+// 32-bit index arithmetic: tsc_create refuses tables with more than 2^31 - 1 elements per array
+#define IDX(row) ((unsigned int)(row) * (unsigned int)S.RS + (unsigned int)r)
 // Vehicle-slot arrays are tiled by 64-replica block: [replica block][slot row][64 lanes].
 // One wavefront's slots of one lane are then a few KB of contiguous memory per field
 // (consecutive rows 512 B apart instead of RS*8 bytes): DRAM-page and TLB friendly.
-#define SIDX(row) ((((size_t)r >> 6) * (size_t)S.n_slots + (size_t)(row)) * 64 + ((size_t)r & 63))
+#define SIDX(row) ((((unsigned int)r >> 6) * (unsigned int)S.n_slots + (unsigned int)(row)) * 64u + ((unsigned int)r & 63u))
 
 struct Tm {
   double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
