@@ -20,6 +20,17 @@
 #define TSC_OB_MAX 3
 
 // One cross of a lane-link, 32 bytes so the wave-uniform scan fetches it with one scalar load.
+// Device-side vehicle template rows: the TSC_TMPL_STRIDE fields of the C-ABI table followed by
+// constants derived from them at create with the very f64 operations the kernels used to
+// spend per vehicle (IEEE division is correctly rounded on both sides: same bits).
+#define TSC_DT_STRIDE 20
+#define TSC_DT_HA_MAX 12   /* 0.5 / maxNegAcc */
+#define TSC_DT_IA_MAX 13   /* 0.5 / (0.5 / maxNegAcc) */
+#define TSC_DT_HA_USUAL 14 /* 0.5 / usualNegAcc */
+#define TSC_DT_IA_USUAL 15 /* 0.5 / (0.5 / usualNegAcc) */
+#define TSC_DT_LIMIT 16    /* maxSpeed * maxSpeed / usualNegAcc / 2 + maxSpeed * interval * 2 (look-ahead limit) */
+#define TSC_DT_HWDEN 17    /* headway + interval / 2 */
+
 // Wave-uniform constants of one work list (k_enum -> k_exec), 128 bytes: everything a
 // batch needs about its drivable and the lane-link it is heading for, in one scalar load.
 struct ListRec {

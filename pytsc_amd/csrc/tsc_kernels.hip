@@ -32,10 +32,12 @@
 
 struct Tm {
   double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
+  // derived per template at create (same f64 operations, host side): see TSC_DT_* in tsc_device.h
+  double hA_max, iA_max, hA_usual, iA_usual, limit, hwden;
 };
 
 __device__ __forceinline__ Tm load_tm(const DevNet &N, int id) {
-  const double *p = N.tmpl + (size_t)id * TSC_TMPL_STRIDE;
+  const double *p = N.tmpl + (size_t)id * TSC_DT_STRIDE;
   Tm t;
   t.len = p[TSC_T_LEN];
   t.maxPosAcc = p[TSC_T_MAXPOSACC];
@@ -47,6 +49,12 @@ __device__ __forceinline__ Tm load_tm(const DevNet &N, int id) {
   t.yieldDist = p[TSC_T_YIELDDIST];
   t.turnSpeed = p[TSC_T_TURNSPEED];
   t.approach = p[TSC_T_APPROACH];
+  t.hA_max = p[TSC_DT_HA_MAX];
+  t.iA_max = p[TSC_DT_IA_MAX];
+  t.hA_usual = p[TSC_DT_HA_USUAL];
+  t.iA_usual = p[TSC_DT_IA_USUAL];
+  t.limit = p[TSC_DT_LIMIT];
+  t.hwden = p[TSC_DT_HWDEN];
   return t;
 }
 
@@ -88,23 +96,23 @@ __device__ __forceinline__ int reach_steps(double cur, double distance, double t
     return (int)ceil((target - cur) / acc / interval) + (int)ceil((distance - dut) / target / interval);
   }
 }
-__device__ __forceinline__ double no_collision_speed(double vL, double dL, double vF, double dF, double gap,
+// a = 0.5 / dF and ia = 0.5 / a of the follower's deceleration dF come from the template table
+__device__ __forceinline__ double no_collision_speed(double vL, double dL, double vF, double a, double ia, double gap,
                                                      double interval, double targetGap) {
   double c = vF * interval / 2 + targetGap - 0.5 * vL * vL / dL - gap;
-  double a = 0.5 / dF;
   double b = 0.5 * interval;
   if (b * b < 4 * a * c) return -100;
-  double v1 = 0.5 / a * (sqrt(b * b - 4 * a * c) - b);
+  double v1 = ia * (sqrt(b * b - 4 * a * c) - b);
   double v2 = 2 * vL - dL * interval + 2 * (gap - targetGap) / interval;
   return min2(v1, v2);
 }
 __device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, double vL, const Tm &tl, double gap,
                                                    double interval) {
-  double s = no_collision_speed(vL, tl.maxNegAcc, speed, t.maxNegAcc, gap, interval, 0);
+  double s = no_collision_speed(vL, tl.maxNegAcc, speed, t.hA_max, t.iA_max, gap, interval, 0);
   double assumeDecel = 0, leaderSpeed = vL;
   if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
-  s = min2(s, no_collision_speed(vL, tl.usualNegAcc, speed, t.usualNegAcc, gap, interval, t.minGap));
-  s = min2(s, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) / (t.headway + interval / 2));
+  s = min2(s, no_collision_speed(vL, tl.usualNegAcc, speed, t.hA_usual, t.iA_usual, gap, interval, t.minGap));
+  s = min2(s, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) / t.hwden);
   return s;
 }
 // distance covered by one more acceleration step followed by usual braking to a stop
@@ -225,7 +233,7 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
     double td = S.tail_dist[IDX(e)];
     int ttag = S.tail_tag[IDX(e)];
     int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
-    double tlen = N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+    double tlen = N.tmpl[(size_t)tt * TSC_DT_STRIDE + TSC_T_LEN];
     double crossDistance = Lo - xo;
     double vehDistance = td - tlen;
     if (crossDistance + vehDistance < 0) {
@@ -243,7 +251,7 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
       double dj = vj.x;
       int tg = S.tag[SIDX(sb + j)];
       int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tg));
-      double tlen = N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+      double tlen = N.tmpl[(size_t)tt * TSC_DT_STRIDE + TSC_T_LEN];
       if (dj > xo && !(dj - xo - tlen <= 0)) continue; // rear already past the cross: next vehicle
       f.d2 = xo - dj;
       f.speed = vj.y;
@@ -524,7 +532,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       const int tid = tmpl_of<SINGLE>(N, vbase, vid);
       const Tm t = load_tm(N, tid);
       const int e_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(e_tt));
-      const double e_len = N.tmpl[(size_t)e_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
+      const double e_len = N.tmpl[(size_t)e_tmpl * TSC_DT_STRIDE + TSC_T_LEN];
 
       // ---- leader and gap (engine: updateLeaderAndGap)
       bool has_leader = false;
@@ -533,11 +541,11 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       if (valid && it > 0) {
         has_leader = true;
         l_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ptag));
-        gap = pd - N.tmpl[(size_t)l_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN] - dist;
+        gap = pd - N.tmpl[(size_t)l_tmpl * TSC_DT_STRIDE + TSC_T_LEN] - dist;
         vL = ps;
       } else if (valid) {
         double dis = L - dist;
-        double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * interval * 2;
+        const double limit = t.limit;
         const int ne = (e_hdr & TSC_CNT_MASK) - ((e_hdr & TSC_NEW_BIT) ? 1 : 0); // tail before this step's insertion
         if (IS_LINK) {
           if (ne > 0) {
@@ -552,7 +560,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           for (int qq = 0; qq < TSC_MAXQ; qq++) {
             if (lr.olk[qq] >= 0 && l_cnt[qq] > 0) {
               int tt = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(l_tt[qq]));
-              double cg = dis + l_td[qq] - N.tmpl[(size_t)tt * TSC_TMPL_STRIDE + TSC_T_LEN];
+              double cg = dis + l_td[qq] - N.tmpl[(size_t)tt * TSC_DT_STRIDE + TSC_T_LEN];
               if (!has_leader || cg < gap) {
                 has_leader = true;
                 gap = cg;
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
           }
         }
         tid = SINGLE ? 0 : N.veh_tmpl[vbase + TSC_TAG_VID(tag2[u])];
-        const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_APPROACH];
+        const double approach = SINGLE ? approach0 : N.tmpl[(size_t)tid * TSC_DT_STRIDE + TSC_T_APPROACH];
         const bool heavy = is == 0 || (L - dist) <= approach;
         bucket = TSC_MAXQ; // plain follower
         if (heavy) {
@@ -887,8 +895,8 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
           // v = 0 and the position is unchanged -- no arithmetic needed.  (The blocker
           // the engine would note for it is never read: only lane heads, vehicles on
           // lane-links and fresh tails are ever registered at a cross.)
-          const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
-          const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
+          const double plen = SINGLE ? len0 : N.tmpl[(size_t)p_tmpl * TSC_DT_STRIDE + TSC_T_LEN];
+          const double mg = SINGLE ? mingap0 : N.tmpl[(size_t)tid * TSC_DT_STRIDE + TSC_T_MINGAP];
           if (p_dist - plen - dist <= mg) settled = true;
         }
         double out_d = dist, out_v = 0.0;
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
           // acceleration, three comparisons.  It cannot reach the lane end in this step.
           const Tm t = load_tm(N, tid);
           const double rest = L - dist;
-          const double limit = t.maxSpeed * t.maxSpeed / t.usualNegAcc / 2 + t.maxSpeed * C.interval * 2;
+          const double limit = t.limit;
           if (rest > limit && rest > t.approach && rest > 2 * t.maxSpeed * C.interval) {
             const bool clear = aux2[u] < 0 || out_links_empty;
             if (clear) {
@@ -1046,8 +1054,8 @@ __device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S,
   if (N.veh_start[vbase + vid] > t_next) return;
   int tid = tmpl_of<SINGLE>(N, vbase, vid);
   if (have_tail) {
-    double tlen = N.tmpl[(size_t)tail_tmpl * TSC_TMPL_STRIDE + TSC_T_LEN];
-    double mg = N.tmpl[(size_t)tid * TSC_TMPL_STRIDE + TSC_T_MINGAP];
+    double tlen = N.tmpl[(size_t)tail_tmpl * TSC_DT_STRIDE + TSC_T_LEN];
+    double mg = N.tmpl[(size_t)tid * TSC_DT_STRIDE + TSC_T_MINGAP];
     if (!(tail_dist > tlen + mg)) return;
   }
   if (w >= N.drv_cap[d]) {
