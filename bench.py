@@ -108,16 +108,12 @@ def main():
     A = tables.n_agents
     eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")))
     torch.manual_seed(0)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(rank)
     buf = eng.observe()
-    nact = eng.n_actions
-    u = torch.empty((R, A, nact), device=dev, dtype=torch.float32)
+    acts = torch.empty((R, A), device=dev, dtype=torch.int32)
 
     def policy(mask):
-        # uniform among mask-valid actions, on device: argmax of U(0,1) * mask
-        u.uniform_(1e-6, 1.0, generator=gen)
-        return (u * mask).argmax(-1).to(torch.int32)
+        # uniform among mask-valid actions, on device, one launch (tsc_random_valid_actions)
+        return eng.random_valid_actions(mask, seed=1234 + rank, out=acts)
 
     def reset_finished(buf):
         # restart() of replicas whose simulated hour is over (pytsc/__init__.py:164-176)

@@ -267,6 +267,17 @@ int tsc_lane_detail(tsc_handle_t h, int32_t *lane_counts_dev,
  *     # bins >= 0 in the outgoing window). */
 int tsc_lane_window_counts(tsc_handle_t h, int32_t *window_counts_dev, void *stream);
 
+/* On-device random policy (reference controllers/controllers.py:245-268,
+ * RandomController: a uniformly random allowable action per signal), fused into one
+ * launch: for every (replica, agent) draws one of the actions whose entry in
+ *  mask_dev      [R, A, n_actions] uint8 (as written by tsc_step / tsc_observe) is non-zero,
+ * into
+ *  actions_dev   [R, A] int32 (0 when no action is allowed).
+ * The draw is a counter-based hash of (seed, number of calls on this handle so far,
+ * replica, agent): reproducible for a seed, independent of the grid shape. */
+int tsc_random_valid_actions(tsc_handle_t h, const uint8_t *mask_dev, uint64_t seed,
+                             int32_t *actions_dev, void *stream);
+
 /* Synchronous dump of one replica's vehicles to HOST arrays (capacity `cap`):
  * drivable index, distance, speed, vid.  Returns the vehicle count (>= 0) or a
  * negative error.  Vehicles inserted for the *next* sub-step are excluded. */

@@ -1872,6 +1872,30 @@ __global__ void k_snapshot(DevNet N, DevState S, int rep, int cap, int *count, i
   }
 }
 
+// Uniformly random allowed action per (replica, agent): one launch instead of a chain of
+// tensor ops (reference RandomController, controllers.py:245-268).
+__global__ void k_random_valid(DevState S, DevCfg C, int A, const unsigned char *mask, unsigned long long seed,
+                               unsigned long long draw, int *actions) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S.R * A) return;
+  const unsigned char *m = mask + (size_t)i * C.n_actions;
+  int allowed = 0;
+  for (int k = 0; k < C.n_actions; k++) allowed += m[k] != 0;
+  // splitmix64 of (seed, draw index, replica * A + agent)
+  unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (draw + 1) + 0xbf58476d1ce4e5b9ull * (unsigned long long)(i + 1);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  int pick = allowed > 0 ? (int)(((z >> 32) * (unsigned long long)allowed) >> 32) : 0;
+  int act = 0;
+  for (int k = 0; k < C.n_actions; k++)
+    if (m[k] != 0 && pick-- == 0) {
+      act = k;
+      break;
+    }
+  actions[i] = act;
+}
+
 __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.R) return;

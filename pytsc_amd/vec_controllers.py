@@ -127,7 +127,8 @@ def sotl(ctx, buf, counts, theta=3, mu=4, phi_min=5):
 
 
 def random_valid(ctx, buf, generator=None):
-    """RandomController (controllers.py:245-268)."""
+    """RandomController (controllers.py:245-268) on tensors; `VecEngine.random_valid_actions`
+    is the same policy fused into one launch of the library."""
     allow = ctx.allowable(buf)
     u = torch.rand(allow.shape, device=allow.device, generator=generator).clamp_min(1e-6)
     return (u * allow).argmax(-1).to(torch.int32)

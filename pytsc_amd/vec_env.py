@@ -125,6 +125,17 @@ class VecEngine:
             _lib.check(n, "tsc_snapshot")
         return drv[:n], dist[:n], speed[:n], vid[:n]
 
+    def random_valid_actions(self, mask, seed=0, out=None):
+        """[R, A] int32: a uniformly random allowed action per signal, one launch
+        (tsc_random_valid_actions; reference RandomController, controllers.py:245-268)."""
+        if out is None:
+            out = torch.empty(mask.shape[:2], dtype=torch.int32, device=self.device)
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and out.is_contiguous()
+        _lib.check(self.lib.tsc_random_valid_actions(self.h, mask.data_ptr(), int(seed), out.data_ptr(),
+                                                     torch.cuda.current_stream(self.device).cuda_stream),
+                   "tsc_random_valid_actions")
+        return out
+
     def errors(self):
         e = C.c_int32(0)
         _lib.check(self.lib.tsc_errors(self.h, C.byref(e)), "tsc_errors")

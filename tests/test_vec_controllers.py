@@ -81,3 +81,37 @@ def test_vectorised_fixed_time_drives_4096_replicas():
     assert trace == [0, 0, 0, 0, 0, 1, 2, 2, 2, 2, 2, 3, 4, 4, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7]
     assert env.engine.errors() == 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_fused_random_valid_actions_are_valid_uniform_and_reproducible():
+    """tsc_random_valid_actions (RandomController, controllers.py:245-268, as one launch)."""
+    import torch
+
+    from pytsc_amd.config import Config
+    from pytsc_amd.scenario import build_tables
+    from pytsc_amd.vec_env import VecEngine
+
+    cfg = Config("syn_2x2", signal={"action_space": "phase_selection", "round_robin": False},
+                 hip={"flow_rate": 600.0, "n_flow_sets": 1, "sim_length": 300})
+    engs = [VecEngine(build_tables(cfg, n_replicas=512), want=("mask",)) for _ in range(2)]
+    bufs = [e.observe() for e in engs]
+    counts = torch.zeros(16, device="cuda")
+    for s in range(30):
+        a0 = engs[0].random_valid_actions(bufs[0]["mask"], seed=7)
+        a1 = engs[1].random_valid_actions(bufs[1]["mask"], seed=7)
+        assert torch.equal(a0, a1)  # same seed, same call index, same masks
+        picked = torch.gather(bufs[0]["mask"], 2, a0.long().unsqueeze(-1))
+        assert bool((picked > 0).all())
+        if s == 0:  # all eight green phases allowed at the start: a flat histogram
+            counts = torch.bincount(a0.flatten(), minlength=16).float()
+            allowed = bufs[0]["mask"][0, 0].bool()
+            frac = counts[allowed] / counts.sum()
+            assert float((frac - 1.0 / int(allowed.sum())).abs().max()) < 0.03
+            assert float(counts[~allowed].sum()) == 0
+        bufs = [e.step(a) for e, a in zip(engs, (a0, a1))]
+    b = engs[0].random_valid_actions(bufs[0]["mask"], seed=8)
+    c = engs[1].random_valid_actions(bufs[1]["mask"], seed=9)
+    assert not torch.equal(b, c)
+    for e in engs:
+        e.close()
