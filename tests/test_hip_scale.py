@@ -201,3 +201,64 @@ def test_mixed_vehicle_templates_match_oracle(oracle_lib):
     assert eng.mean_vehicles() > 100
     assert eng.errors() == 0 and orc.errors() == 0
     eng.close()
+
+
+def _identical_replicas_stay_identical(eng, R, n_sets, A, n_act, steps):
+    """K6 at full size: replicas that share a flow set and receive the same actions hold
+    bit-identical observations and stats; different flow sets differ."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    buf = eng.observe()
+    for s in range(steps):
+        u = torch.rand((n_sets, A, n_act), device="cuda", generator=g).clamp_min(1e-6)
+        acts = (u.repeat(R // n_sets, 1, 1) * buf["mask"]).argmax(-1).to(torch.int32)
+        buf = eng.step(acts)
+    for k in range(n_sets):
+        assert torch.equal(buf["obs"][k::n_sets], buf["obs"][k].expand_as(buf["obs"][k::n_sets]))
+        assert torch.equal(buf["stats"][k::n_sets], buf["stats"][k].expand_as(buf["stats"][k::n_sets]))
+    assert not torch.equal(buf["obs"][0], buf["obs"][1])
+    assert eng.errors() == 0
+    return buf
+
+
+def test_full_size_properties_16x16_r4096():
+    """BASELINE config 2 size (256 agents x 4096 replicas on one GPU)."""
+    from pytsc_amd.vec_env import VecEngine
+
+    R = 4096
+    eng = VecEngine(_tables("syn_16x16", R, flow_rate=700.0, n_flow_sets=2, sim_length=600),
+                    want=("obs", "mask", "stats", "global_reward"))
+    _identical_replicas_stay_identical(eng, R, 2, 256, eng.n_actions, 25)
+    assert eng.mean_vehicles() > 500
+    eng.close()
+
+
+def test_full_size_properties_jinan_r8192():
+    """BASELINE config 4 size: the Jinan 3x4 network with its real flow file, 8192 replicas
+    (one flow set: every replica must stay identical to replica 0 under identical actions,
+    and differ from it under different ones)."""
+    import torch
+
+    from fixtures import load_case
+    from pytsc_amd.vec_env import VecEngine
+
+    R = 8192
+    _, _, _, _, tables = load_case("jinan_3_4_random", n_replicas=R)
+    eng = VecEngine(tables, want=("obs", "mask", "stats"))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    buf = eng.observe()
+    A, n_act = buf["mask"].shape[1], buf["mask"].shape[2]
+    for s in range(40):
+        u = torch.rand((2, A, n_act), device="cuda", generator=g).clamp_min(1e-6)
+        # even replicas follow one action stream, odd replicas another
+        acts = (u.repeat(R // 2, 1, 1) * buf["mask"]).argmax(-1).to(torch.int32)
+        buf = eng.step(acts)
+    for k in range(2):
+        assert torch.equal(buf["obs"][k::2], buf["obs"][k].expand_as(buf["obs"][k::2]))
+        assert torch.equal(buf["stats"][k::2], buf["stats"][k].expand_as(buf["stats"][k::2]))
+    assert not torch.equal(buf["stats"][0], buf["stats"][1])
+    assert eng.mean_vehicles() > 100 and eng.errors() == 0
+    eng.close()
