@@ -188,7 +188,7 @@ def main():
                         "the kernel is latency/occupancy-limited at 4 waves per SIMD, not bandwidth-limited (DESIGN.md §5)",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world_size == 1:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.rows, args.cols, args.rate, min(args.warmup, 120),
                                                 args.cpu_budget)
         print(json.dumps(line))
