@@ -43,7 +43,7 @@ struct ListRec {
   double L, drvMax, my_len, first_cross_x; // drivable length / speed limit, length of `link`, its first cross
   long long item_off;           // start of the list's items in wl_items
   unsigned long long conflict;  // links of the intersection crossing `link`
-  long long pad[2];
+  unsigned int avail4[4];       // lanes: green masks of the four out-links (olk order)
 };
 
 struct CrossRec {

@@ -723,9 +723,11 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   const int r = rb * 64 + lane;
   const bool own_valid = r < S.R;
   const int d = IS_LINK ? N.n_lanes + row : row;
-  const int sb = N.drv_slot_base[d];
-  const double L = N.drv_length[d];
   const int wl0 = IS_LINK ? N.n_lanes * TSC_NLIST + row : row * TSC_NLIST;
+  // the drivable's constants in one 128-byte scalar load (the record of its first list)
+  const ListRec lr0 = S.wl_rec[wl0];
+  const int sb = lr0.sb;
+  const double L = lr0.L;
   int n = 0;
   if (own_valid) {
     n = S.cnt[IDX(d)] & TSC_CNT_MASK;
@@ -742,10 +744,9 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
     }
     return;
   }
-  const int qb = N.lane_out_ptr[d], qe = N.lane_out_ptr[d + 1];
   int olk[TSC_MAXQ];
 #pragma unroll
-  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = (qb + qq < qe) ? N.lane_out_links[qb + qq] : -2;
+  for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = lr0.olk[qq];
   const double approach0 = N.tmpl[TSC_T_APPROACH], len0 = N.tmpl[TSC_T_LEN], mingap0 = N.tmpl[TSC_T_MINGAP];
   const double bd0 = brake_distance_after_accel(0.0, load_tm(N, 0), C.interval);
   // is any vehicle on a lane-link leaving this lane?  (look-ahead of a free-running head; loaded
@@ -758,12 +759,12 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   }
   // which out-links are green in this replica (bit q): a head stopped at a red light is settled here
   int green_bits = 0xf;
-  if (qb < qe && own_valid) {
-    const int raw = S.raw_phase[IDX(N.link_agent[olk[0] - N.n_lanes])];
+  if (lr0.ag >= 0 && own_valid) {
+    const int raw = S.raw_phase[IDX(lr0.ag)];
     green_bits = 0;
 #pragma unroll
     for (int qq = 0; qq < TSC_MAXQ; qq++)
-      if (olk[qq] >= 0 && ((N.link_avail_mask[olk[qq] - N.n_lanes] >> raw) & 1u)) green_bits |= 1 << qq;
+      if (olk[qq] >= 0 && ((lr0.avail4[qq] >> raw) & 1u)) green_bits |= 1 << qq;
   }
   const double2 *__restrict__ g_ds = S.ds;
   double2 *__restrict__ o_ds = S.nds;
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
             if (clear) {
               double v = t.maxSpeed;
               v = min2(v, speed + t.maxPosAcc * C.interval);
-              v = min2(v, N.drv_max_speed[d]);
+              v = min2(v, lr0.drvMax);
               v = min2(v, t.maxSpeed);
               v = max2(v, speed - t.maxNegAcc * C.interval);
               if (!(v < 0)) {
@@ -974,9 +975,20 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
     if (nfz != fz) S.fz[IDX(d)] = nfz;
   }
   __syncthreads();
+  // the five reservations are issued together (one round trip), then the five stores
+  int fbase[TSC_NLIST];
+#pragma unroll
+  for (int q = 0; q < TSC_NLIST; q++) {
+    fbase[q] = 0;
+    if (qn[q] && threadIdx.x == 0) fbase[q] = atomicAdd(&S.wl_cnt[wl0 + q], qn[q]);
+  }
 #pragma unroll
   for (int q = 0; q < TSC_NLIST; q++)
-    if (qn[q]) wl_flush(S, wl0 + q, stage[IS_LINK ? 0 : q], qn[q]);
+    if (qn[q]) {
+      const int base = __builtin_amdgcn_readfirstlane(fbase[q]);
+      if ((int)threadIdx.x < qn[q])
+        S.wl_items[S.wl_rec[wl0 + q].item_off + base + threadIdx.x] = stage[q][threadIdx.x];
+    }
 }
 
 // ------------------------------------------------------------------ k_plan
