@@ -46,6 +46,13 @@ struct ListRec {
   unsigned int avail4[4];       // lanes: green masks of the four out-links (olk order)
 };
 
+// What k_exec needs of an intersection, per replica, in one 32-byte record: the raw phase
+// (k_phase) and the three cross-candidate masks (k_notify).
+struct AgentRec {
+  unsigned long long oe, ov, os;
+  int raw, pad;
+};
+
 struct CrossRec {
   double x;   // distance of the cross on this link
   double xo;  // distance of the cross on the other link
@@ -108,8 +115,8 @@ struct DevState {
   double *lane_sum;
   unsigned int *lane_in_bits, *lane_out_bits;
   // per agent [n_agents * RS]
-  int *cur_idx, *top, *changed, *raw_phase;
-  unsigned long long *occ_e, *occ_v, *occ_s;
+  int *cur_idx, *top, *changed;
+  AgentRec *arec; // raw phase + cross-candidate masks, read together by k_exec
   double *agent_local, *agent_pressure;
   // per replica [RS]
   int *t, *set, *restarts, *fin_cnt;

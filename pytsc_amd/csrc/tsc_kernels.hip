@@ -196,9 +196,10 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
   }
   __syncthreads();
   if (mine && wy == 0) {
-    S.occ_e[IDX(a)] = m_e[lx];
-    S.occ_v[IDX(a)] = m_v[lx];
-    S.occ_s[IDX(a)] = m_s[lx];
+    AgentRec *ar = &S.arec[IDX(a)];
+    ar->oe = m_e[lx];
+    ar->ov = m_v[lx];
+    ar->os = m_s[lx];
   }
 }
 
@@ -473,10 +474,11 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       int raw = 0;
       unsigned long long oe = 0, ov = 0, os_green = 0;
       if (valid && ag >= 0 && !(C.ablate & 32768)) {
-        raw = S.raw_phase[IDX(ag)];
-        oe = S.occ_e[IDX(ag)];
-        ov = S.occ_v[IDX(ag)];
-        os_green = S.occ_s[IDX(ag)];
+        const AgentRec ar = S.arec[IDX(ag)]; // one 32-byte record: one line per item instead of four
+        raw = ar.raw;
+        oe = ar.oe;
+        ov = ar.ov;
+        os_green = ar.os;
       }
       // ---- ONE load group: the item and its list predecessor, the header of the own
       //      link's end lane (look-ahead, canEnter) and, for head vehicles, the tails of all
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   // which out-links are green in this replica (bit q): a head stopped at a red light is settled here
   int green_bits = 0xf;
   if (lr0.ag >= 0 && own_valid) {
-    const int raw = S.raw_phase[IDX(lr0.ag)];
+    const int raw = S.arec[IDX(lr0.ag)].raw;
     green_bits = 0;
 #pragma unroll
     for (int qq = 0; qq < TSC_MAXQ; qq++)
@@ -1391,7 +1393,7 @@ __global__ void k_reset_replica(DevNet N, DevState S, DevCfg C, const unsigned c
     S.cur_idx[IDX(a)] = 0;
     S.top[IDX(a)] = 0;
     S.changed[IDX(a)] = 0;
-    S.raw_phase[IDX(a)] = N.agent_phase_raw[a * TSC_MAX_AGENT_PHASES];
+    S.arec[IDX(a)].raw = N.agent_phase_raw[a * TSC_MAX_AGENT_PHASES];
   }
 }
 
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_phase(DevNet N, DevState S, DevCfg C, c
     S.top[IDX(a)] = C.yellow_time;
   }
   S.cur_idx[IDX(a)] = target;
-  S.raw_phase[IDX(a)] = N.agent_phase_raw[a * TSC_MAX_AGENT_PHASES + target];
+  S.arec[IDX(a)].raw = N.agent_phase_raw[a * TSC_MAX_AGENT_PHASES + target];
 }
 
 // ---------------------------------------------------------------- k_measure
