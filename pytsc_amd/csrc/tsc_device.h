@@ -107,8 +107,8 @@ struct DevState {
   // outbox of this sub-step's leavers: ob = how many (appended with atomics), records [n_drv * TSC_OB_MAX * RS]
   int *obx_slot, *obx_tag, *obx_aux, *obx_blk;
   double *obx_dist, *obx_speed;
-  double *tail_dist, *tail_speed;   // tail record of the committed state (the tail before a spawn)
-  double *ntail_dist, *ntail_speed; // next half: written by k_enum / k_exec (quiet drivables) / k_commit, then swapped in
+  double2 *tail;  // {dist, speed} of the tail of the committed state (the tail before a spawn)
+  double2 *ntail; // next half: written by k_enum / k_exec (quiet drivables) / k_commit, then swapped in
   // per lane [n_lanes * RS]
   int *spawn_cur, *lane_n, *lane_q;
   int *fz; // [lane][replica] k_enum's standing block: fa | fb << 16 (slots (fa, fb] are skipped)

@@ -231,7 +231,8 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
   const double Lo = N.drv_length[other];
   if (oe & bit) {
     const int e = N.link_end_lane[k];
-    double td = S.tail_dist[IDX(e)];
+    const double2 tl_ = S.tail[IDX(e)];
+    double td = tl_.x;
     int ttag = S.tail_tag[IDX(e)];
     int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(ttag));
     double tlen = N.tmpl[(size_t)tt * TSC_DT_STRIDE + TSC_T_LEN];
@@ -239,7 +240,7 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
     double vehDistance = td - tlen;
     if (crossDistance + vehDistance < 0) {
       f.d2 = -(td + crossDistance);
-      f.speed = S.tail_speed[IDX(e)];
+      f.speed = tl_.y;
       f.vid = TSC_TAG_VID(ttag);
       f.tmpl = tt;
     }
@@ -450,8 +451,7 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
         if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
         o_ds[SIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) {
-          S.ntail_dist[IDX(d)] = nd;
-          S.ntail_speed[IDX(d)] = v;
+          S.ntail[IDX(d)] = make_double2(nd, v);
         }
       }
 
@@ -507,8 +507,9 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       }
       if (valid && (IS_LINK ? it == 0 : link >= 0) && !(C.ablate & 65536)) {
         e_hdr = S.cnt[IDX(el)];
-        e_td = S.tail_dist[IDX(el)];
-        e_ts = S.tail_speed[IDX(el)];
+        const double2 et_ = S.tail[IDX(el)];
+        e_td = et_.x;
+        e_ts = et_.y;
         if (!SINGLE) e_tt = S.tail_tag[IDX(el)];
       }
       if (!IS_LINK) {
@@ -520,8 +521,9 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           l_ts[qq] = 0;
           if (lr.olk[qq] >= 0 && valid && it == 0 && !(C.ablate & 16384)) {
             l_cnt[qq] = S.cnt[IDX(lr.olk[qq])] & TSC_CNT_MASK;
-            l_td[qq] = S.tail_dist[IDX(lr.olk[qq])];
-            l_ts[qq] = S.tail_speed[IDX(lr.olk[qq])];
+            const double2 lt_ = S.tail[IDX(lr.olk[qq])];
+            l_td[qq] = lt_.x;
+            l_ts[qq] = lt_.y;
             if (!SINGLE) l_tt[qq] = S.tail_tag[IDX(lr.olk[qq])];
           }
         }
@@ -671,8 +673,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         }
         o_ds[SIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) { // next tail record of a drivable that stays quiet (k_commit redoes it otherwise)
-          S.ntail_dist[IDX(d)] = nd;
-          S.ntail_speed[IDX(d)] = v;
+          S.ntail[IDX(d)] = make_double2(nd, v);
         }
       }
 
@@ -793,8 +794,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
     f_dist = g_ds[SIDX(sb + fb)].x;
     if (!SINGLE) f_tmpl = N.veh_tmpl[vbase + TSC_TAG_VID(S.tag[SIDX(sb + fb)])];
     if (fb == n - 1) { // the tail record follows the last vehicle even when it stands
-      S.ntail_dist[IDX(d)] = f_dist;
-      S.ntail_speed[IDX(d)] = 0.0;
+      S.ntail[IDX(d)] = make_double2(f_dist, 0.0);
     }
   }
 #define TSC_WALKED(sl) ((sl) < n && !((sl) > fa && (sl) <= fb && skip))
@@ -938,8 +938,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
             o_ds[SIDX(sb + is)] = make_double2(out_d, out_v);
           }
           if (is == n - 1) {
-            S.ntail_dist[IDX(d)] = out_d;
-            S.ntail_speed[IDX(d)] = out_v;
+            S.ntail[IDX(d)] = make_double2(out_d, out_v);
           }
         }
         if (!run_final) {
@@ -1342,8 +1341,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   // ---- tail record (the tail BEFORE the next step's insertion)
   if (have_tail) {
-    S.ntail_dist[IDX(d)] = tl_dist;
-    S.ntail_speed[IDX(d)] = tl_speed;
+    S.ntail[IDX(d)] = make_double2(tl_dist, tl_speed);
     S.tail_tag[IDX(d)] = tl_tag;
   }
   S.tail_prev[IDX(d)] = tp;
