@@ -53,6 +53,12 @@ struct AgentRec {
   int raw, pad;
 };
 
+// A vehicle leaving its drivable in this sub-step, as k_exec hands it to k_commit.
+struct ObxRec {
+  double dist, speed;
+  int tag, aux, blk, slot;
+};
+
 struct CrossRec {
   double x;   // distance of the cross on this link
   double xo;  // distance of the cross on the other link
@@ -105,8 +111,7 @@ struct DevState {
   // per drivable [n_drv * RS]
   int *cnt, *ob, *tail_tag, *tail_prev;
   // outbox of this sub-step's leavers: ob = how many (appended with atomics), records [n_drv * TSC_OB_MAX * RS]
-  int *obx_slot, *obx_tag, *obx_aux, *obx_blk;
-  double *obx_dist, *obx_speed;
+  ObxRec *obx; // [drivable][TSC_OB_MAX][replica]: this sub-step's leavers
   double2 *tail;  // {dist, speed} of the tail of the committed state (the tail before a spawn)
   double2 *ntail; // next half: written by k_enum / k_exec (quiet drivables) / k_commit, then swapped in
   // per lane [n_lanes * RS]

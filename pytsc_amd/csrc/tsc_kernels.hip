@@ -663,12 +663,14 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           int ko = atomicAdd(&S.ob[IDX(d)], 1);
           if (ko < TSC_OB_MAX) {
             size_t ox = ((size_t)d * TSC_OB_MAX + ko) * (size_t)S.RS + (size_t)r;
-            S.obx_slot[ox] = it;
-            S.obx_tag[ox] = tag;
-            S.obx_aux[ox] = aux; // lane vehicle with aux < 0: leaves the network
-            S.obx_blk[ox] = new_w;
-            S.obx_dist[ox] = nd;
-            S.obx_speed[ox] = v;
+            ObxRec rec; // one 32-byte record: one line written here, one read by k_commit
+            rec.dist = nd;
+            rec.speed = v;
+            rec.tag = tag;
+            rec.aux = aux; // lane vehicle with aux < 0: leaves the network
+            rec.blk = new_w;
+            rec.slot = it;
+            S.obx[ox] = rec;
           } else atomicAdd(&S.errors[1], 1);
         }
         o_ds[SIDX(sb + it)] = make_double2(nd, v);
@@ -1129,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     const int m = o_feed[0] < TSC_OB_MAX ? o_feed[0] : TSC_OB_MAX;
     for (int k = 0; k < m; k++) {
       size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
-      if (S.obx_aux[ox] == d) {
+      if (S.obx[ox].aux == d) {
         if (n_arr == 0) {
           first_f = f;
           first_k = k;
@@ -1178,13 +1180,13 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   int tp = (hdr & TSC_NEW_BIT) ? -1 : S.tail_prev[IDX(d)];
   // ---- keep / retire
   const size_t oxs = (size_t)d * TSC_OB_MAX * (size_t)S.RS + (size_t)r;
-  const int s0 = m_self > 0 ? S.obx_slot[oxs] : -1;
-  const int s1 = m_self > 1 ? S.obx_slot[oxs + (size_t)S.RS] : -1;
-  const int s2 = m_self > 2 ? S.obx_slot[oxs + 2 * (size_t)S.RS] : -1;
+  const int s0 = m_self > 0 ? S.obx[oxs].slot : -1;
+  const int s1 = m_self > 1 ? S.obx[oxs + (size_t)S.RS].slot : -1;
+  const int s2 = m_self > 2 ? S.obx[oxs + 2 * (size_t)S.RS].slot : -1;
   for (int k = 0; k < m_self; k++) {
     size_t ox = ((size_t)d * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
-    if (!is_link && S.obx_aux[ox] < 0) { // left the network
-      int vid = TSC_TAG_VID(S.obx_tag[ox]);
+    if (!is_link && S.obx[ox].aux < 0) { // left the network
+      int vid = TSC_TAG_VID(S.obx[ox].tag);
       int st0 = N.veh_start[vbase + vid];
       atomicAdd(&S.fin_cnt[r], 1);
       atomicAdd(&S.fin_dsum[r], (unsigned long long)(t_now - st0));
@@ -1280,10 +1282,11 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         if (pass > 0) break;
         best_f = first_f;
         best_ox = ((size_t)first_f * TSC_OB_MAX + first_k) * (size_t)S.RS + (size_t)r;
-        best_nd = S.obx_dist[best_ox];
-        tg = S.obx_tag[best_ox];
-        ns = S.obx_speed[best_ox];
-        nblk = S.obx_blk[best_ox];
+        const ObxRec rec = S.obx[best_ox];
+        best_nd = rec.dist;
+        tg = rec.tag;
+        ns = rec.speed;
+        nblk = rec.blk;
         best_vid = TSC_TAG_VID(tg);
         have_rec = true;
       } else
@@ -1293,10 +1296,10 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         if (m > TSC_OB_MAX) m = TSC_OB_MAX;
         for (int k = 0; k < m; k++) {
           size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
-          int ax = S.obx_aux[ox];
+          int ax = S.obx[ox].aux;
           if (is_link && ax != d) continue; // lanes: every leaver of a feeder link comes here
-          double nd = S.obx_dist[ox];
-          int vid = TSC_TAG_VID(S.obx_tag[ox]);
+          double nd = S.obx[ox].dist;
+          int vid = TSC_TAG_VID(S.obx[ox].tag);
           bool after_last = nd < last_nd || (nd == last_nd && vid > last_vid);
           bool before_best = nd > best_nd || (nd == best_nd && vid < best_vid);
           if (after_last && before_best) {
@@ -1315,9 +1318,10 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         break;
       }
       if (!have_rec) {
-        tg = S.obx_tag[best_ox];
-        ns = S.obx_speed[best_ox];
-        nblk = S.obx_blk[best_ox];
+        const ObxRec rec = S.obx[best_ox];
+        tg = rec.tag;
+        ns = rec.speed;
+        nblk = rec.blk;
       }
       int seq = TSC_TAG_SEQ(tg) + 1;
       int ntag = TSC_MAKE_TAG(best_vid, seq);
