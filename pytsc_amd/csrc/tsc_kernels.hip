@@ -397,16 +397,18 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 #define TSC_EU 1    /* slots enumerated per turn in k_enum */
 #define TSC_MAXQ 4  /* out-links of a lane (checked at create): one work list per out-link */
 #define TSC_NLIST (TSC_MAXQ + 1) /* work lists per lane: one per out-link + plain followers */
-// work item: (replica << 10) | (slot << 1) | is-tail
-#define TSC_ITEM(rep, slot, tail) ((unsigned int)(((unsigned int)(rep) << 10) | ((slot) << 1) | ((tail) ? 1u : 0u)))
+// work item: (replica << 11) | (slot << 2) | has-blocker-word << 1 | is-tail
+#define TSC_ITEM(rep, slot, blk, tail) \
+  ((unsigned int)(((unsigned int)(rep) << 11) | ((slot) << 2) | ((blk) ? 2u : 0u) | ((tail) ? 1u : 0u)))
 #define TSC_ITEM_TAIL(m) ((m) & 1u)
-#define TSC_ITEM_REP(m) ((int)((m) >> 10))
-#define TSC_ITEM_SLOT(m) ((int)(((m) >> 1) & 511u))
+#define TSC_ITEM_BLK(m) (((m) >> 1) & 1u)
+#define TSC_ITEM_REP(m) ((int)((m) >> 11))
+#define TSC_ITEM_SLOT(m) ((int)(((m) >> 2) & 511u))
 
 // ---- a plain follower (item: replica r, slot it >= 1)
 template <bool SINGLE>
 __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, const ListRec &lr, double interval,
-                                            bool valid, int r, int it, bool is_tail, int ablate = 0) {
+                                            bool valid, int r, int it, bool is_tail, bool has_blk) {
   const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
   const int d = lr.d, sb = lr.sb;
   const double L = lr.L, drvMax = lr.drvMax;
@@ -415,14 +417,10 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
   if (valid) {
         const double2 own = g_ds[SIDX(sb + it)];
         const double dist = own.x, speed = own.y;
-        double pd = dist + 10.0, vL = speed;
-        int blkw = 0;
-        if (!(ablate & 8192)) {
-          const double2 lead = g_ds[SIDX(sb + it - 1)];
-          pd = lead.x;
-          vL = lead.y;
-          blkw = S.ab[SIDX(sb + it)].y;
-        }
+        const double2 lead = g_ds[SIDX(sb + it - 1)];
+        const double pd = lead.x, vL = lead.y;
+        // the blocker word is almost always empty: k_enum says in the item whether to fetch it
+        const int blkw = has_blk ? S.ab[SIDX(sb + it)].y : 0;
         int tid = 0, ptid = 0;
         if (!SINGLE) {
           tid = N.veh_tmpl[vbase + TSC_TAG_VID(S.tag[SIDX(sb + it)])];
@@ -742,7 +740,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   if (IS_LINK) {
     // every vehicle on a lane-link takes the full path
     int qn = 0;
-    for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl0, stage[0], qn, i < n, TSC_ITEM(r, i, i == n - 1));
+    for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl0, stage[0], qn, i < n, TSC_ITEM(r, i, 0, i == n - 1));
     if (qn) {
       __syncthreads();
       wl_flush(S, wl0, stage[0], qn);
@@ -955,7 +953,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
         }
       }
       if (__builtin_amdgcn_ballot_w64(bucket >= 0)) {
-        const unsigned int item = TSC_ITEM(r, is, is == n - 1);
+        const unsigned int item = TSC_ITEM(r, is, blkw != 0, is == n - 1);
 #pragma unroll
         for (int q = 0; q < TSC_NLIST; q++) {
           if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
@@ -1045,7 +1043,7 @@ __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) 
       exec_heavy<SINGLE, true>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
     } else if (lr.pick == TSC_MAXQ) {
       exec_follow<SINGLE>(N, S, lr, C.interval, valid, r, valid ? TSC_ITEM_SLOT(it_cur) : 1, valid && TSC_ITEM_TAIL(it_cur),
-                          C.ablate);
+                          valid && TSC_ITEM_BLK(it_cur));
     } else {
       exec_heavy<SINGLE, false>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur));
     }
