@@ -397,15 +397,19 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 #define TSC_EU 1    /* slots enumerated per turn in k_enum */
 #define TSC_MAXQ 4  /* out-links of a lane (checked at create): one work list per out-link */
 #define TSC_NLIST (TSC_MAXQ + 1) /* work lists per lane: one per out-link + plain followers */
-// work item: (replica << 12) | (slot << 3) | route-ends-here << 2 | has-blocker-word << 1 | is-tail
-// (the two flags let k_exec skip the vehicle's {aux, blk} line: aux is the list's lane-link, or -1)
-#define TSC_ITEM(rep, slot, ends, blk, tail) \
-  ((unsigned int)(((unsigned int)(rep) << 12) | ((slot) << 3) | ((ends) ? 4u : 0u) | ((blk) ? 2u : 0u) | ((tail) ? 1u : 0u)))
+// work item: (replica << 13) | (slot << 4) | out-links-empty << 3 | route-ends-here << 2 |
+//            has-blocker-word << 1 | is-tail
+// (flags from k_enum's coalesced walk that spare k_exec scattered lines: aux is the list's
+//  lane-link, or -1; an empty blocker word and empty out-links need not be fetched)
+#define TSC_ITEM(rep, slot, oempty, ends, blk, tail)                                                          \
+  ((unsigned int)(((unsigned int)(rep) << 13) | ((slot) << 4) | ((oempty) ? 8u : 0u) | ((ends) ? 4u : 0u) | \
+                  ((blk) ? 2u : 0u) | ((tail) ? 1u : 0u)))
 #define TSC_ITEM_TAIL(m) ((m) & 1u)
 #define TSC_ITEM_BLK(m) (((m) >> 1) & 1u)
 #define TSC_ITEM_ENDS(m) (((m) >> 2) & 1u)
-#define TSC_ITEM_REP(m) ((int)((m) >> 12))
-#define TSC_ITEM_SLOT(m) ((int)(((m) >> 3) & 511u))
+#define TSC_ITEM_OEMPTY(m) (((m) >> 3) & 1u)
+#define TSC_ITEM_REP(m) ((int)((m) >> 13))
+#define TSC_ITEM_SLOT(m) ((int)(((m) >> 4) & 511u))
 
 // ---- a plain follower (item: replica r, slot it >= 1)
 template <bool SINGLE>
@@ -461,7 +465,8 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
 //      lanes: `pick` = index of the out-link all items of this batch are heading for
 template <bool SINGLE, bool IS_LINK>
 __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, const DevCfg &C, const ListRec &lr,
-                                           bool valid, int r, int it, bool is_tail, bool route_ends, bool has_blk) {
+                                           bool valid, int r, int it, bool is_tail, bool route_ends, bool has_blk,
+                                           bool out_empty) {
   const int d = lr.d, sb = lr.sb, ag = lr.ag;
   const double L = lr.L, drvMax = lr.drvMax, interval = C.interval;
   const int vbase = (SINGLE || !valid) ? 0 : N.set_veh_ptr[S.set[r]];
@@ -522,7 +527,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           l_tt[qq] = 0;
           l_td[qq] = 0;
           l_ts[qq] = 0;
-          if (lr.olk[qq] >= 0 && valid && it == 0 && !(C.ablate & 16384)) {
+          if (lr.olk[qq] >= 0 && valid && it == 0 && !out_empty) {
             l_cnt[qq] = S.cnt[IDX(lr.olk[qq])] & TSC_CNT_MASK;
             const double2 lt_ = S.tail[IDX(lr.olk[qq])];
             l_td[qq] = lt_.x;
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   if (IS_LINK) {
     // every vehicle on a lane-link takes the full path
     int qn = 0;
-    for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl0, stage[0], qn, i < n, TSC_ITEM(r, i, 0, 1, i == n - 1));
+    for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl0, stage[0], qn, i < n, TSC_ITEM(r, i, 0, 0, 1, i == n - 1));
     if (qn) {
       __syncthreads();
       wl_flush(S, wl0, stage[0], qn);
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
         }
       }
       if (__builtin_amdgcn_ballot_w64(bucket >= 0)) {
-        const unsigned int item = TSC_ITEM(r, is, aux2[u] < 0, blkw != 0, is == n - 1);
+        const unsigned int item = TSC_ITEM(r, is, out_links_empty, aux2[u] < 0, blkw != 0, is == n - 1);
 #pragma unroll
         for (int q = 0; q < TSC_NLIST; q++) {
           if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
@@ -1045,13 +1050,13 @@ __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) 
     const int r = TSC_ITEM_REP(it_cur);
     if (skip) {
     } else if (lr.is_link) {
-      exec_heavy<SINGLE, true>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur), false, true);
+      exec_heavy<SINGLE, true>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur), false, true, false);
     } else if (lr.pick == TSC_MAXQ) {
       exec_follow<SINGLE>(N, S, lr, C.interval, valid, r, valid ? TSC_ITEM_SLOT(it_cur) : 1, valid && TSC_ITEM_TAIL(it_cur),
                           valid && TSC_ITEM_BLK(it_cur));
     } else {
       exec_heavy<SINGLE, false>(N, S, C, lr, valid, r, TSC_ITEM_SLOT(it_cur), valid && TSC_ITEM_TAIL(it_cur),
-                                TSC_ITEM_ENDS(it_cur), TSC_ITEM_BLK(it_cur));
+                                TSC_ITEM_ENDS(it_cur), TSC_ITEM_BLK(it_cur), TSC_ITEM_OEMPTY(it_cur));
     }
     if (b2 >= nb) break;
     b = b2;
