@@ -31,6 +31,10 @@
 #define TSC_DT_LIMIT 16    /* maxSpeed * maxSpeed / usualNegAcc / 2 + maxSpeed * interval * 2 (look-ahead limit) */
 #define TSC_DT_HWDEN 17    /* headway + interval / 2 */
 
+#ifndef TSC_ROWPACK
+#define TSC_ROWPACK 2 /* rows of {dist, speed} stored side by side per replica (DIDX) */
+#endif
+
 // Wave-uniform constants of one work list (k_enum -> k_exec), 128 bytes: everything a
 // batch needs about its drivable and the lane-link it is heading for, in one scalar load.
 struct ListRec {

@@ -29,6 +29,13 @@
 // One wavefront's slots of one lane are then a few KB of contiguous memory per field
 // (consecutive rows 512 B apart instead of RS*8 bytes): DRAM-page and TLB friendly.
 #define SIDX(row) ((((unsigned int)r >> 6) * (unsigned int)S.n_slots + (unsigned int)(row)) * 64u + ((unsigned int)r & 63u))
+// {dist, speed} records: TSC_ROWPACK consecutive rows of a replica sit side by side, so a vehicle
+// and its leader -- and the neighbours of a platoon -- share 128-byte lines more often than
+// replicas do (rows are only about one third occupied by moving vehicles).  Slot bases are
+// multiples of TSC_ROWPACK (tsc_create).
+#define DIDX(row)                                                                                        \
+  (((((unsigned int)r >> 6) * ((unsigned int)S.n_slots / TSC_ROWPACK) + ((unsigned int)(row) / TSC_ROWPACK)) * 64u + \
+    ((unsigned int)r & 63u)) * TSC_ROWPACK + ((unsigned int)(row) % TSC_ROWPACK))
 
 struct Tm {
   double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
@@ -249,7 +256,7 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
     int n = S.cnt[IDX(other)] & TSC_CNT_MASK;
     const int sb = N.drv_slot_base[other];
     for (int j = 0; j < n; j++) {
-      const double2 vj = S.ds[SIDX(sb + j)];
+      const double2 vj = S.ds[DIDX(sb + j)];
       double dj = vj.x;
       int tg = S.tag[SIDX(sb + j)];
       int tt = tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tg));
@@ -266,7 +273,7 @@ __device__ __forceinline__ Foe find_foe(const DevNet &N, const DevState &S, int 
   if (f.vid < 0 && (os_green & bit)) {
     const int sl = N.link_start_lane[k];
     const int s0 = N.drv_slot_base[sl];
-    const double2 v0 = S.ds[SIDX(s0)];
+    const double2 v0 = S.ds[DIDX(s0)];
     double ds = v0.x;
     int tg = S.tag[SIDX(s0)];
     f.d2 = (N.drv_length[sl] - ds) + xo;
@@ -421,9 +428,9 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
   const double2 *__restrict__ g_ds = S.ds;
   double2 *__restrict__ o_ds = S.nds;
   if (valid) {
-        const double2 own = g_ds[SIDX(sb + it)];
+        const double2 own = g_ds[DIDX(sb + it)];
         const double dist = own.x, speed = own.y;
-        const double2 lead = g_ds[SIDX(sb + it - 1)];
+        const double2 lead = g_ds[DIDX(sb + it - 1)];
         const double pd = lead.x, vL = lead.y;
         // the blocker word is almost always empty: k_enum says in the item whether to fetch it
         const int blkw = has_blk ? S.ab[SIDX(sb + it)].y : 0;
@@ -453,7 +460,7 @@ __device__ __forceinline__ void exec_follow(const DevNet &N, const DevState &S, 
         }
         const double nd = deltaDis + dist;
         if (nd > L) atomicAdd(&S.errors[3], 1); // cannot happen: more than the approach distance away
-        o_ds[SIDX(sb + it)] = make_double2(nd, v);
+        o_ds[DIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) {
           S.ntail[IDX(d)] = make_double2(nd, v);
         }
@@ -496,7 +503,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       int e_hdr = 0, e_tt = 0;
       double e_td = 0, e_ts = 0;
       if (valid) {
-        const double2 own = g_ds[SIDX(sb + it)];
+        const double2 own = g_ds[DIDX(sb + it)];
         dist = own.x;
         speed = own.y;
         tag = S.tag[SIDX(sb + it)];
@@ -507,7 +514,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         }
         if (!IS_LINK) aux = route_ends ? -1 : lr.link; // the list a lane vehicle is in says where it is heading
         if (it > 0 && !(C.ablate & 131072)) {
-          const double2 lead = g_ds[SIDX(sb + it - 1)];
+          const double2 lead = g_ds[DIDX(sb + it - 1)];
           pd = lead.x;
           ps = lead.y;
           if (!SINGLE) ptag = S.tag[SIDX(sb + it - 1)];
@@ -681,7 +688,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
             S.obx[ox] = rec;
           } else atomicAdd(&S.errors[1], 1);
         }
-        o_ds[SIDX(sb + it)] = make_double2(nd, v);
+        o_ds[DIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) { // next tail record of a drivable that stays quiet (k_commit redoes it otherwise)
           S.ntail[IDX(d)] = make_double2(nd, v);
         }
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
   double f_dist = 0;
   int f_tmpl = 0;
   if (skip) {
-    f_dist = g_ds[SIDX(sb + fb)].x;
+    f_dist = g_ds[DIDX(sb + fb)].x;
     if (!SINGLE) f_tmpl = N.veh_tmpl[vbase + TSC_TAG_VID(S.tag[SIDX(sb + fb)])];
     if (fb == n - 1) { // the tail record follows the last vehicle even when it stands
       S.ntail[IDX(d)] = make_double2(f_dist, 0.0);
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
     c_aux[u] = -1;
     if (TSC_WALKED(u)) {
       const int sl = u;
-      const double2 v_ = g_ds[SIDX(sb + sl)];
+      const double2 v_ = g_ds[DIDX(sb + sl)];
       const int2 m_ = S.ab[SIDX(sb + sl)];
       c_dist[u] = v_.x;
       c_speed[u] = v_.y;
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
     for (int u = 0; u < TSC_EU; u++)
       if (TSC_WALKED(i + TSC_EU + u)) {
         const int sl = i + TSC_EU + u;
-        const double2 v_ = g_ds[SIDX(sb + sl)];
+        const double2 v_ = g_ds[DIDX(sb + sl)];
         const int2 m_ = S.ab[SIDX(sb + sl)];
         c_dist[u] = v_.x;
         c_speed[u] = v_.y;
@@ -945,7 +952,7 @@ __global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, 
             S.nbbv[IDX(TSC_TAG_VID(S.tag[SIDX(sb + is)]))] = -1;
           }
           if (!(C.ablate & 512)) {
-            o_ds[SIDX(sb + is)] = make_double2(out_d, out_v);
+            o_ds[DIDX(sb + is)] = make_double2(out_d, out_v);
           }
           if (is == n - 1) {
             S.ntail[IDX(d)] = make_double2(out_d, out_v);
@@ -1088,7 +1095,7 @@ __device__ __forceinline__ void spawn_if_due(const DevNet &N, const DevState &S,
   }
   const int2 rr_ = N.veh_rrange[vbase + vid];
   int rb_ = rr_.x, re_ = rr_.y;
-  q_ds[SIDX(sb + w)] = make_double2(0.0, 0.0);
+  q_ds[DIDX(sb + w)] = make_double2(0.0, 0.0);
   S.tag[SIDX(sb + w)] = TSC_MAKE_TAG(vid, 0);
   S.ab[SIDX(sb + w)] = make_int2((rb_ + 1 < re_) ? N.route_drv[rb_ + 1] : -1, 0);
   S.bbv[IDX(vid)] = -1;
@@ -1212,7 +1219,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     if (n > 0) {
       have_tail = true;
       old_tail_kept = true;
-      const double2 tv = q_ds[SIDX(sb + n - 1)];
+      const double2 tv = q_ds[DIDX(sb + n - 1)];
       tl_dist = tv.x;
       tl_speed = tv.y;
       tl_tag = S.tag[SIDX(sb + n - 1)];
@@ -1230,14 +1237,14 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (i + u < n) {
-            vv[u] = q_ds[SIDX(sb + i + u)];
+            vv[u] = q_ds[DIDX(sb + i + u)];
             mm[u] = S.ab[SIDX(sb + i + u)];
             tg[u] = S.tag[SIDX(sb + i + u)];
           }
 #pragma unroll
         for (int u = 0; u < 4; u++)
           if (i + u < n) {
-            q_ds[SIDX(sb + i + u - k)] = vv[u];
+            q_ds[DIDX(sb + i + u - k)] = vv[u];
             S.ab[SIDX(sb + i + u - k)] = mm[u];
             S.tag[SIDX(sb + i + u - k)] = tg[u];
             tl_dist = vv[u].x;
@@ -1251,11 +1258,11 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     } else {
       for (int i = 0; i < n; i++) {
         if (i == s0 || i == s1 || i == s2) continue;
-        const double2 vi = q_ds[SIDX(sb + i)];
+        const double2 vi = q_ds[DIDX(sb + i)];
         double nd = vi.x, ns = vi.y;
         int tg = S.tag[SIDX(sb + i)];
         if (w != i) {
-          q_ds[SIDX(sb + w)] = vi;
+          q_ds[DIDX(sb + w)] = vi;
           S.tag[SIDX(sb + w)] = tg;
           S.ab[SIDX(sb + w)] = S.ab[SIDX(sb + i)];
         }
@@ -1341,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         const int2 rr = N.veh_rrange[vbase + best_vid]; // the vehicle's slice of route_drv
         naux = (rr.x + seq + 1 < rr.y) ? N.route_drv[rr.x + seq + 1] : -1;
       }
-      q_ds[SIDX(sb + w)] = make_double2(best_nd, ns);
+      q_ds[DIDX(sb + w)] = make_double2(best_nd, ns);
       S.tag[SIDX(sb + w)] = ntag;
       S.ab[SIDX(sb + w)] = make_int2(naux, nblk);
       have_tail = true;
@@ -1501,7 +1508,7 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
     double2 v[4];
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (i0 + u < n) v[u] = S.ds[SIDX(sb + i0 + u)];
+      if (i0 + u < n) v[u] = S.ds[DIDX(sb + i0 + u)];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (i0 + u >= n) continue;
@@ -1562,7 +1569,7 @@ __global__ void k_posmat(DevNet N, DevState S, DevCfg C, double *posmat, int max
   if (bins <= 0) return;
   double bin_size = len / bins;
   for (int i = 0; i < n; i++) {
-    const double2 vi = S.ds[SIDX(sb + i)];
+    const double2 vi = S.ds[DIDX(sb + i)];
     double pos = round6(vi.x);
     if (pos < 0) pos = 0;
     else if (pos > len) pos = len;
@@ -1889,7 +1896,7 @@ __global__ void k_snapshot(DevNet N, DevState S, int rep, int cap, int *count, i
     if (k < cap) {
       drv[k] = d;
       slot[k] = i;
-      const double2 vi = S.ds[SIDX(sb + i)];
+      const double2 vi = S.ds[DIDX(sb + i)];
       dist[k] = vi.x;
       speed[k] = vi.y;
       vid[k] = TSC_TAG_VID(S.tag[SIDX(sb + i)]);
