@@ -401,7 +401,7 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 // leaves most lanes idle (23 % of VALU lanes active in the v1 kernel); the engine's
 // update is Jacobi (every decision reads only committed state), so vehicles can be
 // executed in any grouping.
-#define TSC_EU 1    /* slots enumerated per turn in k_enum */
+#define TSC_EU 2    /* slots enumerated per turn in k_enum */
 #define TSC_MAXQ 4  /* out-links of a lane (checked at create): one work list per out-link */
 #define TSC_NLIST (TSC_MAXQ + 1) /* work lists per lane: one per out-link + plain followers */
 // work item: (replica << 13) | (slot << 4) | out-links-empty << 3 | route-ends-here << 2 |
@@ -732,7 +732,7 @@ __device__ __forceinline__ void wl_put(const DevState &S, int list, unsigned int
 
 // ------------------------------------------------------------------ k_enum
 template <bool SINGLE>
-__global__ __launch_bounds__(64, 7) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
+__global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, int n_rb, int n_rows) {
   __shared__ unsigned int stage[TSC_NLIST][TSC_STAGE];
   int rb, row;
   if (!map_block(n_rb, n_rows, rb, row)) return;
