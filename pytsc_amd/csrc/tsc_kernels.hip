@@ -506,7 +506,9 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         const double2 own = g_ds[DIDX(sb + it)];
         dist = own.x;
         speed = own.y;
-        tag = S.tag[SIDX(sb + it)];
+        // the tag (vehicle id) of a single-template lane vehicle is only needed by the cross scan,
+        // a blocker change or a hand-off: fetched there, not for every item
+        if (!SINGLE || IS_LINK) tag = S.tag[SIDX(sb + it)];
         if (IS_LINK || has_blk) { // lane-links: aux is the entry time; else only a non-empty blocker word needs the line
           const int2 om = S.ab[SIDX(sb + it)];
           aux = om.x;
@@ -547,7 +549,8 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       // a head-of-lane candidate only counts while its link is green (engine: notifyCross)
       if (ag >= 0) os_green &= N.agent_phase_avail[(size_t)ag * 32 + raw];
       const double my_len = lr.my_len;
-      const int vid = TSC_TAG_VID(tag);
+      bool have_tag = valid && (!SINGLE || IS_LINK);
+      int vid = TSC_TAG_VID(tag);
       const int tid = tmpl_of<SINGLE>(N, vbase, vid);
       const Tm t = load_tm(N, tid);
       const int e_tmpl = SINGLE ? 0 : tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(e_tt));
@@ -651,6 +654,11 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
               if (bd < lr.first_cross_x + (L - dist) - t.yieldDist) scan = false;
             } else scan = false;
           }
+          if (scan && !have_tag) {
+            tag = S.tag[SIDX(sb + it)];
+            vid = TSC_TAG_VID(tag);
+            have_tag = true;
+          }
           if (!(C.ablate & 16))
             cross_scan<SINGLE>(N, S, r, vbase, lr, scan, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green,
                                interval, s, nblk, C.ablate);
@@ -670,9 +678,14 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         int old_b = TSC_BLK_VID(blkw);
         int new_w = ((nblk + 1) & 0xffffff) | ((old_b >= 0) ? (1 << 30) : 0);
         if (new_w != blkw) S.ab[SIDX(sb + it)].y = new_w;
-        if (nblk >= 0 || old_b >= 0 || TSC_BLK_OLDER(blkw)) S.nbbv[IDX(vid)] = nblk;
+        const bool touch_bbv = nblk >= 0 || old_b >= 0 || TSC_BLK_OLDER(blkw);
         // ---- move (engine: setDeltaDistance)
         double nd = deltaDis + dist;
+        if (!have_tag && (touch_bbv || nd > L)) {
+          tag = S.tag[SIDX(sb + it)];
+          vid = TSC_TAG_VID(tag);
+        }
+        if (touch_bbv) S.nbbv[IDX(vid)] = nblk;
         if (nd > L) {
           nd -= L;
           int ko = atomicAdd(&S.ob[IDX(d)], 1);
