@@ -964,9 +964,9 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
             S.ab[SIDX(sb + is)].y = (TSC_BLK_VID(blkw) >= 0) ? (1 << 30) : 0;
             S.nbbv[IDX(TSC_TAG_VID(S.tag[SIDX(sb + is)]))] = -1;
           }
-          if (!(C.ablate & 512)) {
-            o_ds[DIDX(sb + is)] = make_double2(out_d, out_v);
-          }
+          // (the first slot of a standing block was settled in the previous sub-step as well: the
+          //  other half already holds this very record)
+          if (!(settled && skip && is == fa)) o_ds[DIDX(sb + is)] = make_double2(out_d, out_v);
           if (is == n - 1) {
             S.ntail[IDX(d)] = make_double2(out_d, out_v);
           }
