@@ -240,6 +240,15 @@ int tsc_destroy(tsc_handle_t h);
  * initial_wait_time warm-up sub-steps. */
 int tsc_reset(tsc_handle_t h, const uint8_t *reset_mask_dev, void *stream);
 
+/* tsc_reset with the flow set of each restarted replica chosen by the caller:
+ * set_index_dev[R] int32, taken modulo n_sets; a negative entry (or a NULL
+ * pointer) keeps tsc_reset's rule.  This is how `flow_rate_type: random`
+ * (reference backends/cityflow/config.py:63-76: random.choice(flow_files) at
+ * every simulated-hour restart) is served: the host side draws, as the reference
+ * does, and hands the draw over. */
+int tsc_reset_sets(tsc_handle_t h, const uint8_t *reset_mask_dev,
+                   const int32_t *set_index_dev, void *stream);
+
 /* One env step for all replicas: apply actions_dev[R, A], advance delta_time
  * engine sub-steps, measure, and fill the requested outputs.  An action of -1
  * leaves that signal untouched (phase and time_on_phase), as when the reference

@@ -32,6 +32,7 @@ def load():
     lib.tsco_destroy.argtypes = [C.c_void_p]
     lib.tsco_errors.argtypes = [C.c_void_p]
     lib.tsco_reset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.tsco_reset_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tsco_observe.argtypes = [C.c_void_p, C.POINTER(TscStepOut)]
     lib.tsco_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(TscStepOut)]
     lib.tsco_lane_detail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
@@ -105,9 +106,11 @@ class Oracle:
     def errors(self):
         return self.lib.tsco_errors(self.h)
 
-    def reset(self, mask=None):
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data
-        self.lib.tsco_reset(self.h, m)
+    def reset(self, mask=None, sets=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        s = None if sets is None else np.ascontiguousarray(sets, np.int32)
+        self.lib.tsco_reset_sets(self.h, None if m is None else m.ctypes.data,
+                                 None if s is None else s.ctypes.data)
 
     def observe(self):
         self.lib.tsco_observe(self.h, C.byref(self.out.struct))

@@ -639,12 +639,14 @@ static void engine_step(orc_t *o, rep_t *r) {
 }
 
 /* ---------------------------------------------------------------- lifecycle */
-static void rep_reset(orc_t *o, rep_t *r, int rep_index, int advance_set) {
+static void rep_reset(orc_t *o, rep_t *r, int rep_index, int advance_set, int forced_set) {
   const tsc_net_t *n = &o->net;
   if (advance_set) {
     if (o->cfg.sequential_sets) r->restarts += 1;
   }
   r->set = (o->cfg.set_offset + rep_index + r->restarts) % o->fl.n_sets;
+  /* flow_rate_type "random" (backends/cityflow/config.py:63-76): the caller's draw */
+  if (forced_set >= 0) r->set = forced_set % o->fl.n_sets;
   r->n_veh = o->fl.set_veh_ptr[r->set + 1] - o->fl.set_veh_ptr[r->set];
   r->step = 0;
   int base = o->fl.set_veh_ptr[r->set];
@@ -723,7 +725,7 @@ void *tsco_create(const tsc_net_t *net, const tsc_flows_t *fl, const tsc_config_
     r->lane_sum_speed = (double *)calloc((size_t)net->n_lanes, sizeof(double));
     r->lane_posmat = (double *)calloc((size_t)net->n_lanes * (size_t)max_bins, sizeof(double));
     r->restarts = 0;
-    rep_reset(o, r, i, 0);
+    rep_reset(o, r, i, 0, -1);
   }
   return o;
 }
@@ -1059,15 +1061,17 @@ static void fill_outputs(orc_t *o, int ri, const tsc_step_out_t *out) {
 }
 
 /* ---------------------------------------------------- env-level API (host) */
-int tsco_reset(void *h, const uint8_t *mask) {
+int tsco_reset_sets(void *h, const uint8_t *mask, const int32_t *sets) {
   orc_t *o = (orc_t *)h;
   for (int i = 0; i < o->cfg.n_replicas; i++) {
     if (mask && !mask[i]) continue;
-    rep_reset(o, &o->rep[i], i, 1);
+    rep_reset(o, &o->rep[i], i, 1, sets ? sets[i] : -1);
     for (int s = 0; s < o->cfg.initial_wait_time; s++) engine_step(o, &o->rep[i]);
   }
   return 0;
 }
+
+int tsco_reset(void *h, const uint8_t *mask) { return tsco_reset_sets(h, mask, NULL); }
 
 int tsco_observe(void *h, const tsc_step_out_t *out) {
   orc_t *o = (orc_t *)h;

@@ -45,7 +45,16 @@ class Simulator:
             self.tables.cfg.action_space = 0
             self.engine = self.engine_factory(self.tables, int(sim.get("device", 0)))
         else:
-            self.engine.reset()
+            # restart in place; for `random` / `sequential` demand the flow file the config just
+            # chose (reference config.py:63-76) is handed to the engine as the replicas' flow set
+            files = list(sim.get("flow_files") or [])
+            sets = None
+            if sim.get("flow_rate_type", "constant") != "constant" and self.config.flow_file in files:
+                sets = np.full(n_replicas, files.index(self.config.flow_file), dtype=np.int32)
+            if sets is not None:
+                self.engine.reset(sets=torch.as_tensor(sets))
+            else:
+                self.engine.reset()
         self.cityflow_retriever = self.retriever = Retriever(self)
         self.stepped = False
         self._staged = {}

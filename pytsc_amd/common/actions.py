@@ -1,7 +1,5 @@
 """Action spaces (reference: pytsc/common/actions.py:87-211).  `apply` stages the
 per-signal targets; the engine consumes them in the next simulator_step."""
-import random
-
 from pytsc_amd.common.utils import pad_list
 
 
@@ -10,17 +8,6 @@ class BaseActionSpace:
         self.config = config
         self.traffic_signals = traffic_signals
         self.ts_ids = list(traffic_signals.keys())
-
-    def get_trad_controller_actions(self, controller):
-        actions = []
-        mask = self.get_mask()
-        for i, ts in enumerate(self.traffic_signals.values()):
-            if controller == "random":
-                action = random.choices(range(ts.controller.n_phases), weights=mask[i])[0]
-            else:
-                action = ts.get_controller_action(controller)
-            actions.append(action)
-        return actions
 
 
 class PhaseSelectionActionSpace(BaseActionSpace):
@@ -58,14 +45,3 @@ class PhaseSwitchActionSpace(BaseActionSpace):
             nxt = (cur + 1) % ts.controller.n_phases
             masks.append([1 if allow[cur] else 0, 1 if allow[nxt] else 0])
         return masks
-
-    def get_trad_controller_actions(self, controller):
-        actions = []
-        mask = self.get_mask()
-        for i, ts in enumerate(self.traffic_signals.values()):
-            if controller == "random":
-                action = random.choices([0, 1], weights=mask[i])[0]
-            else:
-                action = ts.get_controller_action(controller)
-            actions.append(1 if ts.controller.program.current_phase_index != action else 0)
-        return actions

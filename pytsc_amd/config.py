@@ -82,17 +82,16 @@ class Config:
         random.seed(self.simulator["seed"])
 
     def _set_flow_file(self):
-        """Flow-file selection per (re)start (backends/cityflow/config.py:63-76)."""
+        """Which flow file the next (re)start uses (reference backends/cityflow/config.py:63-76):
+        `constant` -> flow_file; `random` -> a draw of Python's global `random` (seeded in
+        __init__, as the reference does) over flow_files; `sequential` -> the next of the cycle."""
         kind = self.simulator.get("flow_rate_type", "constant")
-        if kind == "constant":
-            self.flow_file = self.simulator.get("flow_file")
-        elif kind == "random":
-            self.flow_file = random.choice(self.simulator["flow_files"])
-        elif kind == "sequential":
-            self.flow_file = next(self.flow_files_cycle)
-        else:
-            raise ValueError(
-                "Flow files order is not supported. "
-                + "Flow files order must be `random` or `constant`"
-            )
+        pick = {
+            "constant": lambda: self.simulator.get("flow_file"),
+            "random": lambda: random.choice(self.simulator["flow_files"]),
+            "sequential": lambda: next(self.flow_files_cycle),
+        }.get(kind)
+        if pick is None:
+            raise ValueError(f"flow_rate_type {kind!r}: expected constant, random or sequential")
+        self.flow_file = pick()
         return self.flow_file

@@ -122,7 +122,8 @@ struct DevState {
   int *spawn_cur, *lane_n, *lane_q;
   int *fz; // [lane][replica] k_enum's standing block: fa | fb << 16 (slots (fa, fb] are skipped)
   double *lane_sum;
-  unsigned int *lane_in_bits, *lane_out_bits;
+  unsigned long long *lane_in_bits; // 3 predicate bits per incoming-window bin (visibility <= 16)
+  unsigned int *lane_out_bits;
   // per agent [n_agents * RS]
   int *cur_idx, *top, *changed;
   AgentRec *arec; // raw phase + cross-candidate masks, read together by k_exec

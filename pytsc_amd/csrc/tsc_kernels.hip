@@ -23,6 +23,18 @@
 // (compiled with -ffp-contract=off on both sides) so results are bit-identical.
 #include "tsc_device.h"
 
+// Diagnostic ablation switches (tools/ablate_action.py) exist only in -DTSC_DIAG builds; the
+// product library has none of them in its kernels.
+#ifdef TSC_DIAG
+#define TSC_ABL(bits) (C.ablate & (bits))
+#define TSC_ABLP(v, bits) ((v) & (bits))
+#define TSC_ABLV C.ablate
+#else
+#define TSC_ABL(bits) 0
+#define TSC_ABLP(v, bits) 0
+#define TSC_ABLV 0
+#endif
+
 // 32-bit index arithmetic: tsc_create refuses tables with more than 2^31 - 1 elements per array
 #define IDX(row) ((unsigned int)(row) * (unsigned int)S.RS + (unsigned int)r)
 // Vehicle-slot arrays are tiled by 64-replica block: [replica block][slot row][64 lanes].
@@ -369,10 +381,10 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
   for (int e = cb; e < ce; e++) {
     const CrossRec nxt = N.cross_rec[e + 1];
     const bool want = !stop && cur.x >= dts && ((active >> (cur.meta & 255)) & 1ull);
-    if (__builtin_amdgcn_ballot_w64(want) && !(ablate & 128)) {
+    if (__builtin_amdgcn_ballot_w64(want) && !TSC_ABLP(ablate, 128)) {
       if (want) {
         Foe f = find_foe<SINGLE>(N, S, r, vbase, cur.other, cur.meta & 255, cur.xo, oe, ov, os_green);
-        if (f.vid >= 0 && !(ablate & 64)) {
+        if (f.vid >= 0 && !TSC_ABLP(ablate, 64)) {
           double d1 = cur.x - dts;
           if (!cross_can_pass(N, S, r, speed, t, vid, ell, t1, cur.meta >> 8, d1, f, interval)) {
             s = min2(s, stop_before_speed(speed, t, cur.x - dts - t.yieldDist, interval));
@@ -485,7 +497,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       // signal phase and cross-candidate masks of the item's replica: loaded with the item
       int raw = 0;
       unsigned long long oe = 0, ov = 0, os_green = 0;
-      if (valid && ag >= 0 && !(C.ablate & 32768)) {
+      if (valid && ag >= 0 && !TSC_ABL(32768)) {
         const AgentRec ar = S.arec[IDX(ag)]; // one 32-byte record: one line per item instead of four
         raw = ar.raw;
         oe = ar.oe;
@@ -515,14 +527,14 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
           blkw = om.y;
         }
         if (!IS_LINK) aux = route_ends ? -1 : lr.link; // the list a lane vehicle is in says where it is heading
-        if (it > 0 && !(C.ablate & 131072)) {
+        if (it > 0 && !TSC_ABL(131072)) {
           const double2 lead = g_ds[DIDX(sb + it - 1)];
           pd = lead.x;
           ps = lead.y;
           if (!SINGLE) ptag = S.tag[SIDX(sb + it - 1)];
         }
       }
-      if (valid && (IS_LINK ? it == 0 : link >= 0) && !(C.ablate & 65536)) {
+      if (valid && (IS_LINK ? it == 0 : link >= 0) && !TSC_ABL(65536)) {
         e_hdr = S.cnt[IDX(el)];
         const double2 et_ = S.tail[IDX(el)];
         e_td = et_.x;
@@ -617,12 +629,12 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
       int nblk = -1;
       if (IS_LINK) {
         double s = t.maxSpeed;
-        if (!(C.ablate & 16))
+        if (!TSC_ABL(16))
           cross_scan<SINGLE>(N, S, r, vbase, lr, valid, speed, t, vid, aux, dist, oe, ov, os_green, interval, s, nblk,
-                             C.ablate);
+                             TSC_ABLV);
         v = min2(v, s);
       } else {
-        const bool related = has_link && (L - dist) <= t.approach && !(C.ablate & 1);
+        const bool related = has_link && (L - dist) <= t.approach && !TSC_ABL(1);
         if (__builtin_amdgcn_ballot_w64(related)) {
           double s = t.maxSpeed;
           bool done = !related;
@@ -659,9 +671,9 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
             vid = TSC_TAG_VID(tag);
             have_tag = true;
           }
-          if (!(C.ablate & 16))
+          if (!TSC_ABL(16))
             cross_scan<SINGLE>(N, S, r, vbase, lr, scan, speed, t, vid, 0x7fffffff, -(L - dist), oe, ov, os_green,
-                               interval, s, nblk, C.ablate);
+                               interval, s, nblk, TSC_ABLV);
           if (related) v = min2(v, s);
         }
       }
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
   //      just masked off).  Slot fa -- whose own leader may have moved -- is walked like
   //      any other; k_commit drops the block when slots shift.
   int fa = 0, fb = 0, fz = 0;
-  if (own_valid && !(C.ablate & 8)) {
+  if (own_valid && !TSC_ABL(8)) {
     fz = S.fz[IDX(d)];
     fa = fz & 0xffff;
     fb = fz >> 16;
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
             if (olk[qq] == aux2[u]) bucket = qq;
         }
         bool settled = false;
-        if (u == 0 && is == 0 && speed == 0 && aux2[u] >= 0 && !((green_bits >> bucket) & 1) && !(C.ablate & 4096)) {
+        if (u == 0 && is == 0 && speed == 0 && aux2[u] >= 0 && !((green_bits >> bucket) & 1) && !TSC_ABL(4096)) {
           // The head of a lane standing at a red light, too close to the stop line to take
           // one more acceleration step: the stop-line bound of getNextSpeed is 0 (its
           // link is not available and it can brake), no cross is scanned (so no blocker),
@@ -934,7 +946,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
         }
         double out_d = dist, out_v = 0.0;
         bool finished = settled;
-        if (u == 0 && is == 0 && !settled && !(C.ablate & 8192)) {
+        if (u == 0 && is == 0 && !settled && !TSC_ABL(8192)) {
           // A lane head farther from the lane end than the look-ahead limit, with no vehicle
           // on any lane-link leaving the lane (or leaving the network at the lane end): no
           // leader within reach, not yet concerned by the signal or the crosses -- free
@@ -987,7 +999,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
 #pragma unroll
         for (int q = 0; q < TSC_NLIST; q++) {
           if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
-          if (!(C.ablate & 256)) wl_put(S, wl0 + q, stage[IS_LINK ? 0 : q], qn[q], bucket == q, item);
+          if (!TSC_ABL(256)) wl_put(S, wl0 + q, stage[IS_LINK ? 0 : q], qn[q], bucket == q, item);
         }
       }
       p_dist = dist;
@@ -1066,7 +1078,7 @@ __global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) 
       total = S.wl_cnt[list2];
       item = (j2 * 64 + lane < total) ? S.wl_items[S.wl_rec[list2].item_off + j2 * 64 + lane] : 0u;
     }
-    const bool skip = !lr.is_link && (((C.ablate & 1024) && lr.pick == TSC_MAXQ) || ((C.ablate & 2048) && lr.pick != TSC_MAXQ));
+    const bool skip = !lr.is_link && ((TSC_ABL(1024) && lr.pick == TSC_MAXQ) || (TSC_ABL(2048) && lr.pick != TSC_MAXQ));
     const int r = TSC_ITEM_REP(it_cur);
     if (skip) {
     } else if (lr.is_link) {
@@ -1409,13 +1421,15 @@ __global__ __launch_bounds__(256) void k_reset(DevNet N, DevState S, DevCfg C, c
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
 }
 
-__global__ void k_reset_replica(DevNet N, DevState S, DevCfg C, const unsigned char *mask, int first) {
+__global__ void k_reset_replica(DevNet N, DevState S, DevCfg C, const unsigned char *mask, const int *sets, int first) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.R) return;
   if (mask && !mask[r]) return;
   int restarts = first ? 0 : S.restarts[r] + (C.sequential_sets ? 1 : 0);
   S.restarts[r] = restarts;
-  S.set[r] = (C.set_offset + r + restarts) % N.n_sets;
+  int set = (C.set_offset + r + restarts) % N.n_sets;
+  if (sets && sets[r] >= 0) set = sets[r] % N.n_sets; // the caller's draw (flow_rate_type: random)
+  S.set[r] = set;
   S.t[r] = -1;
   S.fin_cnt[r] = 0;
   S.fin_dsum[r] = 0;
@@ -1549,12 +1563,12 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
     }
   }
   // 3 predicate bits per incoming-window bin: occupied (>= 0), zero (== 0), >= 1
-  unsigned int ib = 0;
+  unsigned long long ib = 0; // 3 bits x MAX_VIS (16) bins = 48 bits
   for (int b = 0; b < vis; b++) {
     const unsigned int one = (in_one >> b) & 1u, two = (in_two >> b) & 1u;
-    if (one) ib |= 1u << (3 * b);
-    if (one && !two && ((in_zero >> b) & 1u)) ib |= 2u << (3 * b);
-    if (two || (one && ((in_ge1 >> b) & 1u))) ib |= 4u << (3 * b);
+    if (one) ib |= 1ull << (3 * b);
+    if (one && !two && ((in_zero >> b) & 1u)) ib |= 2ull << (3 * b);
+    if (two || (one && ((in_ge1 >> b) & 1u))) ib |= 4ull << (3 * b);
   }
   S.lane_n[IDX(l)] = n;
   S.lane_q[IDX(l)] = q;
@@ -1611,10 +1625,11 @@ __global__ void k_lane_window_counts(DevNet N, DevState S, DevCfg C, int *out, i
   int l = lblk * (int)blockDim.y + (int)threadIdx.y;
   int r = rb * 64 + threadIdx.x;
   if (l >= N.n_lanes || r >= S.R) return;
-  unsigned int ib = S.lane_in_bits[IDX(l)], ob = S.lane_out_bits[IDX(l)];
+  const unsigned long long ib = S.lane_in_bits[IDX(l)];
+  const unsigned int ob = S.lane_out_bits[IDX(l)];
   int nz = 0, no = 0;
   for (int b = 0; b < C.visibility; b++) {
-    unsigned int t3 = (ib >> (3 * b)) & 7u;
+    unsigned int t3 = (unsigned int)(ib >> (3 * b)) & 7u;
     nz += (t3 >> 1) & 1u;
     no += t3 & 1u;
   }
@@ -1733,9 +1748,9 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
       for (int k = N.agent_inc_ptr[a]; k < N.agent_inc_ptr[a + 1]; k++) {
         int l = N.agent_inc_lanes[k];
         for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
-        unsigned int bits = S.lane_in_bits[IDX(l)];
+        const unsigned long long bits = S.lane_in_bits[IDX(l)];
         for (int b = 0; b < vis; b++) {
-          unsigned int t3 = (bits >> (3 * b)) & 7u;
+          unsigned int t3 = (unsigned int)(bits >> (3 * b)) & 7u;
           // kept iff value > 0: occupied and not exactly zero; value = trunc(clip(v, 0, 1))
           if ((t3 & 1u) && !(t3 & 2u)) row[w++] = (t3 & 4u) ? 2 : 1;
         }

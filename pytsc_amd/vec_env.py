@@ -74,12 +74,21 @@ class VecEngine:
         except Exception:
             pass
 
-    def reset(self, mask=None):
-        m = None
+    def reset(self, mask=None, sets=None):
+        """Restart the replicas selected by `mask` ([R] uint8, None = all).  `sets` ([R] int32)
+        names the flow set each restarted replica uses from now on (flow_rate_type: random,
+        reference backends/cityflow/config.py:63-76); None / negative entries keep the handle's rule."""
+        m = s = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             m = C.c_void_p(mask.data_ptr())
-        _lib.check(self.lib.tsc_reset(self.h, m, self._stream()), "tsc_reset")
+        if sets is not None:
+            sets = torch.as_tensor(sets).to(device=self.device, dtype=torch.int32).contiguous()
+            if sets.shape != (self.R,):
+                raise ValueError(f"sets must be [{self.R}]")
+            s = C.c_void_p(sets.data_ptr())
+        self._last_reset_args = (mask, sets)  # keep alive until the kernels have run
+        _lib.check(self.lib.tsc_reset_sets(self.h, m, s, self._stream()), "tsc_reset_sets")
 
     def observe(self):
         _lib.check(self.lib.tsc_observe(self.h, C.byref(self.out), self._stream()), "tsc_observe")
@@ -176,6 +185,7 @@ class VecTrafficSignalNetwork:
         self.agent_ids = list(self.parsed_network.traffic_signals.keys())
         self.buf = self.engine.observe()
         self.episode_count = 0
+        self._set_rng = torch.Generator().manual_seed(int(self.config.simulator["seed"]))
 
     @property
     def episode_limit(self):
@@ -218,8 +228,16 @@ class VecTrafficSignalNetwork:
         return self.buf["global_reward"], self.buf["done"], self.get_env_info()
 
     def restart(self):
-        """Restart the replicas whose simulated hour is over (pytsc/__init__.py:164-176)."""
-        self.engine.reset(self.buf["terminated"])
+        """Restart the replicas whose simulated hour is over (pytsc/__init__.py:164-176): the
+        reference rebuilds the signals and measures again, so masks / observations / phases
+        describe the fresh state afterwards.  `flow_rate_type: random` draws a flow set per
+        restarted replica (backends/cityflow/config.py:63-76), here from a seeded torch generator."""
+        sets = None
+        if self.config.simulator.get("flow_rate_type", "constant") == "random" and self.tables.flows.n_sets > 1:
+            sets = torch.randint(0, int(self.tables.flows.n_sets), (self.n_replicas,), generator=self._set_rng,
+                                 dtype=torch.int32)
+        self.engine.reset(self.buf["terminated"], sets=sets)
+        self.buf = self.engine.observe()
 
     def reset_all(self):
         self.engine.reset()

@@ -65,7 +65,9 @@ class VecEPyMARLTrafficSignalNetwork:
         """As the reference wrapper: counts an episode, returns the current obs/state,
         restarts only the replicas whose simulated hour is over."""
         self.episode_count += 1
-        obs, state = self.get_obs(), self.get_state()
+        # the reference returns the observation taken BEFORE the restart (wrappers/epymarl.py:97-102);
+        # restart() measures again into the same device buffers, hence the copies
+        obs, state = self.get_obs().clone(), self.get_state().clone()
         self.tsc_env.restart()
         return obs, state
 

@@ -21,8 +21,8 @@ class OracleEngine:
                  "agent_stats", "phase", "local_reward64", "global_reward64")
         return {k: torch.from_numpy(getattr(out, k).copy()) for k in names}
 
-    def reset(self, mask=None):
-        self.o.reset(None if mask is None else np.asarray(mask))
+    def reset(self, mask=None, sets=None):
+        self.o.reset(None if mask is None else np.asarray(mask), None if sets is None else np.asarray(sets))
 
     def observe(self):
         return self._buf(self.o.observe())

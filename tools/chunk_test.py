@@ -30,5 +30,6 @@ def run(K, streams=1, warm=120, steps=120):
         e.close()
     print(f"K={K} streams={streams}: {R * 16 * steps / dt / 1e6:.2f} M agent-env-steps/s, {dt / steps * 1e3:.3f} ms/step, {v:.0f} veh/replica", flush=True)
 
-for K, st in ((1, 1), (2, 1), (4, 1), (8, 1), (4, 2), (8, 2), (8, 4)):
-    run(K, st)
+if __name__ == "__main__":
+    for K, st in ((1, 1), (2, 1), (4, 1), (8, 1), (4, 2), (8, 2), (8, 4)):
+        run(K, st)
