@@ -1,23 +1,31 @@
 """Benchmark of the step() hot path: agent-env-steps/s on the 4x4 grid.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one env step of every replica: apply actions -> 5 engine sub-steps ->
-measure -> observations / rewards / masks (tsc_step through the C-ABI), driven by
-an on-device random-valid-action policy.  Inputs are synthetic (Poisson demand,
-SURVEY.md §8(d) config 2) and resident in HBM before the timed region.  Replicas
-shard across ranks with no collective on the step path (weak scaling: 4096
-replicas per GPU); torch.distributed is used only for the barrier around the
-timed region and the max-over-ranks of the elapsed time.
+measure -> observations / rewards / masks / info stats (tsc_step through the C-ABI),
+driven by an on-device random-valid-action policy.  Inputs are synthetic (Poisson
+demand) and resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0) with the throughput, the roofline object of the
-dominant kernel (k_exec, timed live with HIP events on its stream) and the CPU
-baseline (the scalar oracle on one host core, bounded sample).
+* N > 1 and no WORLD_SIZE in the environment: this process -- before any GPU call --
+  starts N worker processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set),
+  waits for them and fails loudly if one fails or the node has fewer than N GPUs.
+  Under `python -m torch.distributed.run` it is a worker straight away.
+* Replicas shard across ranks with no collective on the step path (weak scaling:
+  --replicas per GPU); torch.distributed (RCCL) is used only for the barrier around
+  the timed region and the max-over-ranks of the elapsed time.
+* Every run first rolls all replicas forward to the network's steady state (until the
+  mean number of live vehicles stops rising) OUTSIDE the timed region, whatever
+  --warmup says; then W untimed warm-up steps, then exactly K timed steps.
+* Rank 0 prints ONE JSON line: throughput, the roofline object of the dominant kernel
+  (timed live with HIP events on its stream) and, at N = 1, the CPU baseline (the scalar
+  oracle -- a restatement, not CityFlow -- on 1 host core and on all host cores,
+  measured before the GPU is touched).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +34,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X"
+DEFAULT_OUTPUTS = "obs,mask,local_reward,global_reward,done,terminated,stats"
 
 
 def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets):
@@ -40,19 +50,17 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets):
     return build_tables(cfg, n_replicas=n_replicas, set_offset=set_offset)
 
 
-def cpu_baseline(rows, cols, rate, warmup, budget_s):
-    """The scalar f64 CPU oracle ("port": a restatement, not CityFlow) on ONE host
-    core, same network + demand (flow set 0), same random-valid policy; bounded
-    sample.  Test-infrastructure code used here only as the measured baseline."""
+# ------------------------------------------------------------------ CPU baseline
+def _cpu_worker(tables, seed, warmup, budget_s, start_at, q):
+    """One process: the scalar f64 oracle on one replica of the workload, random valid
+    actions, `warmup` untimed env steps, then as many env steps as fit in budget_s."""
     import numpy as np
 
     from oracle.pyoracle import Oracle
 
-    tables = workload_tables(rows, cols, 1, 0, rate, 1)
     orc = Oracle(tables)
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     out = orc.observe()
-    A = tables.n_agents
 
     def act(mask):
         u = rng.random(mask.shape) * mask
@@ -60,6 +68,8 @@ def cpu_baseline(rows, cols, rate, warmup, budget_s):
 
     for _ in range(warmup):
         out = orc.step(act(out.mask[0])[None])
+    while time.time() < start_at:  # all workers enter the timed region together
+        time.sleep(0.001)
     n, t0 = 0, time.perf_counter()
     while True:
         out = orc.step(act(out.mask[0])[None])
@@ -70,43 +80,160 @@ def cpu_baseline(rows, cols, rate, warmup, budget_s):
         dt = time.perf_counter() - t0
         if dt >= budget_s:
             break
+    q.put((n, dt))
+
+
+def cpu_baseline(rows, cols, rate, warmup, budget_s):
+    """The CPU oracle ("port": a restatement, NOT CityFlow) on this box's host cores: one
+    process on one core, then one process per core.  Runs BEFORE anything touches the GPU
+    (fork is only safe then).  Test-infrastructure code, used here only as the measured baseline."""
+    import multiprocessing as mp
+
+    from oracle import pyoracle
+
+    pyoracle.build()
+    tables = workload_tables(rows, cols, 1, 0, rate, 1)  # built once, shared with the workers by fork
+    A = tables.n_agents
+    ctx = mp.get_context("fork")
+    n_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def run(n_procs, budget):
+        q = ctx.Queue()
+        start_at = time.time() + 0.5 + 0.02 * n_procs
+        procs = [ctx.Process(target=_cpu_worker, args=(tables, i, warmup, budget, start_at, q)) for i in range(n_procs)]
+        for p in procs:
+            p.start()
+        res = [q.get() for _ in procs]
+        for p in procs:
+            p.join()
+        return sum(A * n / dt for n, dt in res), sum(n for n, _ in res), max(dt for _, dt in res)
+
+    v1, n1, dt1 = run(1, budget_s)
+    vall, nall, dtall = (v1, n1, dt1) if n_cores == 1 else run(n_cores, budget_s)
     return {
-        "value": A * n / dt, "unit": "agent-env-steps/s", "cores": 1, "kind": "port",
-        "sample": f"CPU restatement (oracle), not CityFlow: 1 replica of the same {rows}x{cols} "
-                  f"workload, {n} env steps after {warmup} warm-up steps, {dt:.1f} s on 1 of "
-                  f"{os.cpu_count()} host cores",
+        "value": vall, "unit": "agent-env-steps/s", "cores": n_cores, "kind": "port",
+        "value_1core": v1,
+        "sample": f"CPU restatement (oracle), not CityFlow: 1 replica of the same {rows}x{cols} workload per "
+                  f"process, random valid actions, {warmup} untimed env steps (network filling) then {dtall:.1f} s "
+                  f"timed; {n_cores} processes (one per host core): {nall} env steps; 1 process on 1 core: "
+                  f"{n1} env steps in {dt1:.1f} s",
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
-    ap.add_argument("--warmup", type=int, default=120)
-    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
-    ap.add_argument("--rows", type=int, default=4)
-    ap.add_argument("--cols", type=int, default=4)
-    ap.add_argument("--rate", type=float, default=700.0, help="veh/h per entry road")
-    ap.add_argument("--flow-sets", type=int, default=8)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--outputs", default="obs,mask,local_reward,global_reward,done,terminated")
-    args = ap.parse_args()
+# ------------------------------------------------------------------ launcher
+def launch_workers(args, argv):
+    """--gpus N > 1 without a distributed launcher: start N fresh worker processes.  Nothing in
+    this process has touched the GPU (torch.cuda.device_count() does not initialise it)."""
+    n = args.gpus
+    if not args.stub:
+        import torch
 
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} requested but this node has {have} GPU(s)\n")
+            return 2
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: worker exit codes {rcs}\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------ stub (launcher test only)
+class _StubEngine:
+    """CPU stand-in used ONLY by tests/test_bench_launcher.py (--stub) to drive the multi-process
+    path (spawn, rendezvous, barrier, max-over-ranks, one JSON line) without a GPU.  Its line is
+    labelled "data": "stub" and measures nothing."""
+
+    def __init__(self, R, A):
+        import torch
+
+        self.R, self.A = R, A
+        self.buf = {"mask": torch.ones((R, A, 2), dtype=torch.uint8), "terminated": torch.zeros(R, dtype=torch.uint8)}
+        self.kernel = "stub"
+
+    def observe(self):
+        return self.buf
+
+    def step(self, actions):
+        time.sleep(0.001)
+        return self.buf
+
+    def random_valid_actions(self, mask, seed=0, out=None):
+        return out
+
+    def reset(self, mask=None):
+        pass
+
+    def mean_vehicles(self):
+        return 0.0
+
+    def errors(self):
+        return 0
+
+    def profile(self, on):
+        pass
+
+    def profile_read(self):
+        return 0.0, 0
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------ worker
+def preroll(eng, policy, buf, max_steps=400, chunk=25, tol=0.01):
+    """Roll the replicas forward until the mean number of live vehicles stops rising (the
+    4x4 / 700 veh/h network fills for ~150 env steps), so that the timed region measures the
+    steady state whatever --warmup says.  Returns (buf, env steps done, V per replica)."""
+    done, prev = 0, -1.0
+    v = eng.mean_vehicles()
+    while done < max_steps:
+        for _ in range(chunk):
+            buf = eng.step(policy(buf["mask"]))
+        done += chunk
+        v = eng.mean_vehicles()
+        if prev >= 0 and v <= prev * (1.0 + tol):
+            break
+        prev = v
+    return buf, done, v
+
+
+def worker(args):
     import torch
 
     from pytsc_amd import sharding
-    from pytsc_amd.vec_env import VecEngine
 
-    rank, local_rank, world_size = sharding.init()
-    if world_size != args.gpus and world_size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    rank, local_rank, world_size = sharding.init(backend="gloo" if args.stub else None)
+    if world_size != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}")
+    cpu_line = None
+    if not args.stub and not args.no_cpu_baseline and world_size == 1:
+        # first, before the GPU is initialised in this process (the baseline forks workers)
+        cpu_line = cpu_baseline(args.rows, args.cols, args.rate, args.cpu_warmup, args.cpu_budget)
     R = args.replicas
-    tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, args.flow_sets)
-    A = tables.n_agents
-    eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")))
+    if args.stub:
+        dev, A = "cpu", 16
+        eng = _StubEngine(R, A)
+    else:
+        from pytsc_amd.vec_env import VecEngine
+
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, args.flow_sets)
+        A = tables.n_agents
+        eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")), family=args.family)
+    red_dev = dev if (world_size > 1 and not args.stub) else "cpu"
     torch.manual_seed(0)
     buf = eng.observe()
     acts = torch.empty((R, A), device=dev, dtype=torch.int32)
@@ -115,90 +242,138 @@ def main():
         # uniform among mask-valid actions, on device, one launch (tsc_random_valid_actions)
         return eng.random_valid_actions(mask, seed=1234 + rank, out=acts)
 
-    def reset_finished(buf):
-        # restart() of replicas whose simulated hour is over (pytsc/__init__.py:164-176)
-        eng.reset(buf["terminated"])
+    n_env_steps = 0
 
-    check_every = 720 // 4
-    for i in range(args.warmup):
-        buf = eng.step(policy(buf["mask"]))
-        if (i + 1) % check_every == 0:
-            reset_finished(buf)
-    torch.cuda.synchronize(dev)
+    def advance(buf, n):
+        nonlocal n_env_steps
+        for _ in range(n):
+            buf = eng.step(policy(buf["mask"]))
+            n_env_steps += 1
+            if n_env_steps % 180 == 0:
+                # restart() of replicas whose simulated hour is over (pytsc/__init__.py:164-176);
+                # the restarted replicas are measured again so that masks describe the fresh state
+                eng.reset(buf["terminated"])
+                buf = eng.observe()
+        return buf
+
+    pre_steps = 0
+    if not args.no_preroll and not args.stub:
+        buf, pre_steps, _ = preroll(eng, policy, buf)
+        n_env_steps += pre_steps
+    buf = advance(buf, args.warmup)
+    if not args.stub:
+        torch.cuda.synchronize(dev)
     v0 = eng.mean_vehicles()
-    eng.profile(4)  # HIP-event bracket around k_exec on every 4th sub-step (rotates over the 5 positions)
+    eng.profile(4)  # HIP-event bracket around the dominant kernel on every 4th launch
     sharding.barrier()
-    torch.cuda.synchronize(dev)
+    if not args.stub:
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        buf = eng.step(policy(buf["mask"]))
-        if (i + 1) % check_every == 0:
-            reset_finished(buf)
-    torch.cuda.synchronize(dev)
+    buf = advance(buf, args.steps)
+    if not args.stub:
+        torch.cuda.synchronize(dev)
     sharding.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, device=dev if world_size > 1 else "cpu")
+    elapsed = sharding.max_over_ranks(elapsed, device=red_dev)
     k_ms, k_n = eng.profile_read()
     eng.profile(False)
     v1 = eng.mean_vehicles()
     errors = eng.errors()
-    total_units = sharding.sum_over_ranks(R * A * args.steps, device=dev if world_size > 1 else "cpu")
+    total_units = sharding.sum_over_ranks(R * A * args.steps, device=red_dev)
+    v_mean = sharding.sum_over_ranks(0.5 * (v0 + v1), device=red_dev) / world_size
     value = total_units / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank == 0:
-        # roofline of the dominant kernel: algorithmic bytes per
-        # agent-env-step B = 48*V_a + 1356; one k_exec launch
-        # advances R*A agents by one of the delta_time sub-steps = R*A/5 units.
-        va = 0.5 * (v0 + v1) / A
+        kinfo = getattr(eng, "kernel_info", None) or {}
+        # roofline of the dominant kernel: algorithmic bytes per agent-env-step
+        # B = 48*V_a + 1356; one launch advances R*A agents by
+        # kinfo["substeps_per_launch"] of the delta_time sub-steps.
+        va = v_mean / A
         bytes_per_unit = 48.0 * va + 1356.0
-        units_per_launch = R * A / 5.0
+        units_per_launch = R * A * kinfo.get("substeps_per_launch", 1) / 5.0
         avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
         achieved = bytes_per_unit * units_per_launch / avg_launch_s / 1e9 if k_n else None
-        # HBM-side bytes per k_exec launch from the committed PMC passes (profiles/, separate
-        # rocprofv3 runs: counters cannot be read inside this process), at this run's duration
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read inside this process;
+        # they come from the committed separate rocprofv3 --pmc passes (profiles/), and are quoted only
+        # when this run is in the state those passes were taken in (V_a within 10 %).
         traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        tpath = os.path.join(REPO, "profiles", kinfo.get("traffic_file", "none"))
         if k_n and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj["bytes_per_launch"] / avg_launch_s / 1e9
-            traffic_src = "profiles/r01_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) per k_exec launch"
+            if (tj.get("replicas") == R and tj.get("V_a") and abs(va - tj["V_a"]) <= 0.10 * tj["V_a"]
+                    and tj.get("kernel") == kinfo.get("name")):
+                traffic = tj["bytes_per_launch"] / avg_launch_s / 1e9
+                traffic_src = f"profiles/{kinfo['traffic_file']}: {tj.get('formula', '')} at V_a {tj['V_a']:.1f}"
+                if traffic > HBM_PEAK_GBS:  # cannot be: the counters over-count this access pattern
+                    traffic, traffic_src = None, traffic_src + " (rejected: above peak)"
         line = {
-            "metric": "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X",
+            "metric": METRIC if not args.stub else "STUB (launcher test)",
             "value": value, "unit": "agent-env-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub" if args.stub else "synthetic",
             "config": {
                 "workload": f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson "
                             f"{args.rate:g} veh/h per entry road, {R} env replicas per GPU, "
                             f"phase_selection action space, random valid actions, "
                             f"outputs {args.outputs}",
                 "replicas_per_gpu": R, "agents": A, "sub_steps_per_env_step": 5,
-                "mean_live_vehicles_per_replica": 0.5 * (v0 + v1), "device_errors": errors,
+                "state": "steady" if pre_steps else "as-started",
+                "preroll_env_steps": pre_steps,
+                "mean_live_vehicles_per_replica": v_mean, "V_a": va, "device_errors": errors,
+                "kernel_family": kinfo.get("family"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "k_exec (dense 64-item batches of lane / lane-link work items)",
+                "kernel": kinfo.get("name"), "kernel_note": kinfo.get("note"),
                 "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
                 "bytes_per_agent_env_step": bytes_per_unit, "V_a": va,
-                "note": "memory-side traffic is several times the algorithmic bytes (scattered 16-byte records cost 64-byte requests); "
-                        "the kernel is latency/occupancy-limited at 4 waves per SIMD, not bandwidth-limited (DESIGN.md §5)",
             },
         }
-        if not args.no_cpu_baseline and world_size == 1:  # reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(args.rows, args.cols, args.rate, min(args.warmup, 120),
-                                                args.cpu_budget)
-        print(json.dumps(line))
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        print(json.dumps(line), flush=True)
     eng.close()
     if world_size > 1:
         import torch.distributed as dist
 
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
+    ap.add_argument("--rows", type=int, default=4)
+    ap.add_argument("--cols", type=int, default=4)
+    ap.add_argument("--rate", type=float, default=700.0, help="veh/h per entry road")
+    ap.add_argument("--flow-sets", type=int, default=8)
+    ap.add_argument("--family", default="auto", help="kernel family: auto | list | resident")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-preroll", action="store_true", help="diagnostic: time the network as started")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds per CPU-baseline leg")
+    ap.add_argument("--cpu-warmup", type=int, default=150, help="untimed env steps of the CPU baseline")
+    ap.add_argument("--outputs", default=DEFAULT_OUTPUTS)
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher test only
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_workers(args, argv)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -300,6 +300,12 @@ int tsc_errors(tsc_handle_t h, int32_t *n_errors);
  * (synchronous; used for reporting V_a). */
 int tsc_mean_vehicles(tsc_handle_t h, double *mean);
 
+/* Vehicle bookkeeping of every replica: counts_dev [R, 3] int32 = (vehicles that have entered the
+ * network since the last restart, vehicles running now, vehicles that have finished).  entered ==
+ * running + finished is the conservation invariant (Engine.get_vehicle_count() is the second column,
+ * reference retriever.py:108-112). */
+int tsc_replica_counts(tsc_handle_t h, int32_t *counts_dev, void *stream);
+
 /* Kernel timing with HIP events on the stream the kernels are launched on:
  * while enabled (on = n > 0), the launch of the dominant kernel (k_exec, one per
  * engine sub-step) is bracketed by an event pair on every n-th sub-step (an event

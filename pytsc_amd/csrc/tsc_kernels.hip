@@ -1967,4 +1967,21 @@ __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total
   atomicAdd(total, c);
 }
 
+// Vehicle bookkeeping per replica (conservation check K5): entered the network so far, running,
+// finished.  A vehicle inserted for the NEXT sub-step counts in none of the three.
+__global__ void k_replica_counts(DevNet N, DevState S, int *out) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.R) return;
+  int entered = 0, running = 0;
+  for (int d = 0; d < N.n_drv; d++) {
+    int hdr = S.cnt[IDX(d)];
+    int nw = (hdr & TSC_NEW_BIT) ? 1 : 0;
+    running += (hdr & TSC_CNT_MASK) - nw;
+    if (d < N.n_lanes) entered += S.spawn_cur[IDX(d)] - nw;
+  }
+  out[r * 3 + 0] = entered;
+  out[r * 3 + 1] = running;
+  out[r * 3 + 2] = S.fin_cnt[r];
+}
+
 #include "tsc_api.inc"

@@ -23,7 +23,7 @@ class VecEngine:
 
     def __init__(self, tables, device=0, want=("obs", "state", "mask", "local_reward", "global_reward",
                                               "done", "terminated", "stats", "agent_stats", "phase",
-                                              "local_reward64", "global_reward64")):
+                                              "local_reward64", "global_reward64"), family="auto"):
         if not torch.cuda.is_available():
             raise RuntimeError("pytsc_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _lib.load()
@@ -143,6 +143,13 @@ class VecEngine:
         _lib.check(self.lib.tsc_random_valid_actions(self.h, mask.data_ptr(), int(seed), out.data_ptr(),
                                                      torch.cuda.current_stream(self.device).cuda_stream),
                    "tsc_random_valid_actions")
+        return out
+
+    def replica_counts(self):
+        """[R, 3] int32: vehicles entered so far, running, finished (entered == running + finished)."""
+        out = torch.zeros((self.R, 3), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.tsc_replica_counts(self.h, C.c_void_p(out.data_ptr()), self._stream()),
+                   "tsc_replica_counts")
         return out
 
     def errors(self):

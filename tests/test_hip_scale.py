@@ -103,6 +103,8 @@ def test_full_size_properties_4x4_r4096():
     assert not torch.equal(obs[0], obs[1])
     mean_veh = eng.mean_vehicles()
     assert 100 < mean_veh < 3000
+    c = eng.replica_counts().cpu().numpy()  # K5: entered == running + finished, every replica
+    assert np.array_equal(c[:, 0], c[:, 1] + c[:, 2]) and c[:, 0].min() > 0
     assert eng.errors() == 0
     eng.close()
 
