@@ -14,9 +14,9 @@ demand) and resident in HBM before the timed region.
 * Replicas shard across ranks with no collective on the step path (weak scaling:
   --replicas per GPU); torch.distributed (RCCL) is used only for the barrier around
   the timed region and the max-over-ranks of the elapsed time.
-* Every run first rolls all replicas forward to the network's steady state (until the
-  mean number of live vehicles stops rising) OUTSIDE the timed region, whatever
-  --warmup says; then W untimed warm-up steps, then exactly K timed steps.
+* Every run first rolls all replicas forward by a fixed 150 env steps (the network is then
+  filled) OUTSIDE the timed region, whatever --warmup says; then W untimed warm-up steps,
+  then exactly K timed steps.
 * Rank 0 prints ONE JSON line: throughput, the roofline object of the dominant kernel
   (timed live with HIP events on its stream) and, at N = 1, the CPU baseline (the scalar
   oracle -- a restatement, not CityFlow -- on 1 host core and on all host cores,
@@ -192,21 +192,18 @@ class _StubEngine:
 
 
 # ------------------------------------------------------------------ worker
-def preroll(eng, policy, buf, max_steps=400, chunk=25, tol=0.01):
-    """Roll the replicas forward until the mean number of live vehicles stops rising (the
-    4x4 / 700 veh/h network fills for ~150 env steps), so that the timed region measures the
-    steady state whatever --warmup says.  Returns (buf, env steps done, V per replica)."""
-    done, prev = 0, -1.0
-    v = eng.mean_vehicles()
-    while done < max_steps:
-        for _ in range(chunk):
-            buf = eng.step(policy(buf["mask"]))
-        done += chunk
-        v = eng.mean_vehicles()
-        if prev >= 0 and v <= prev * (1.0 + tol):
-            break
-        prev = v
-    return buf, done, v
+PREROLL_ENV_STEPS = 150
+
+
+def preroll(eng, policy, buf, n_steps=PREROLL_ENV_STEPS):
+    """Roll every replica forward by a fixed 150 env steps (750 simulated seconds) OUTSIDE the timed
+    region, whatever --warmup says: the 4x4 / 700 veh/h network fills for about 100 env steps (the
+    driver's `--warmup 5 --steps 20` would otherwise time a network one sixth full).  Under a random
+    policy the vehicle count keeps creeping up afterwards (no true steady state short of gridlock), so
+    the line reports the V_a the timed region actually ran at."""
+    for _ in range(n_steps):
+        buf = eng.step(policy(buf["mask"]))
+    return buf, n_steps, eng.mean_vehicles()
 
 
 def worker(args):
@@ -319,7 +316,7 @@ def worker(args):
                             f"phase_selection action space, random valid actions, "
                             f"outputs {args.outputs}",
                 "replicas_per_gpu": R, "agents": A, "sub_steps_per_env_step": 5,
-                "state": "steady" if pre_steps else "as-started",
+                "state": "filled" if pre_steps else "as-started",
                 "preroll_env_steps": pre_steps,
                 "mean_live_vehicles_per_replica": v_mean, "V_a": va, "device_errors": errors,
                 "kernel_family": kinfo.get("family"),

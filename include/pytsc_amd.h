@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TSC_ABI_VERSION 1
+#define TSC_ABI_VERSION 2
 
 /* error codes */
 #define TSC_OK 0
@@ -86,6 +86,18 @@ extern "C" {
 /* action spaces (reference: common/actions.py:87,134) */
 #define TSC_ACT_PHASE_SELECTION 0
 #define TSC_ACT_PHASE_SWITCH 1
+
+/* Kernel families (same results, bit for bit):
+ *   LIST      state in HBM, replica-fastest arrays, one wavefront = 64 replicas of one drivable,
+ *             dense work lists across replicas, ~27 launches per env step; any network size.
+ *   RESIDENT  one workgroup per replica, the replica's whole state in LDS across the delta_time
+ *             sub-steps and the measurement, ONE launch per env step; networks whose replica fits
+ *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the
+ *             tables do not fit it.
+ *   AUTO      RESIDENT where it fits, else LIST. */
+#define TSC_FAMILY_AUTO 0
+#define TSC_FAMILY_LIST 1
+#define TSC_FAMILY_RESIDENT 2
 
 /* stats columns of tsc_step's `stats` output (reference: backends/cityflow/metrics.py:221-260) */
 #define TSC_N_STATS 8
@@ -209,6 +221,8 @@ typedef struct tsc_config {
   double interval;               /* engine dt (1.0)                               */
   double veh_size_min_gap;       /* 7.5                                           */
   double flickering_coef;        /* 0.01                                          */
+  int32_t kernel_family;         /* TSC_FAMILY_*: which kernel family steps the replicas */
+  int32_t resident_capacity;     /* resident family: vehicle records per replica (0 = default) */
 } tsc_config_t;
 
 /* Optional outputs of tsc_step; any pointer may be NULL (skipped). */
@@ -314,6 +328,9 @@ int tsc_replica_counts(tsc_handle_t h, int32_t *counts_dev, void *stream);
  * of bracketed launches since enable, and clears the accumulators. */
 int tsc_profile_enable(tsc_handle_t h, int on);
 int tsc_profile_read(tsc_handle_t h, double *total_ms, int32_t *n_launches);
+
+/* The kernel family the handle runs (TSC_FAMILY_LIST / TSC_FAMILY_RESIDENT). */
+int tsc_kernel_family(tsc_handle_t h);
 
 /* Sizes derived from the tables. */
 int tsc_obs_size(tsc_handle_t h);

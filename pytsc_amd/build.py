@@ -6,6 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "tsc_kernels.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "tsc_api.inc"), os.path.join(HERE, "csrc", "tsc_device.h"),
+        os.path.join(HERE, "csrc", "tsc_resident.inc"),
         os.path.join(HERE, "..", "include", "pytsc_amd.h")]
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libpytsc_amd.so")

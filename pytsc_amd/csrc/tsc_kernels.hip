@@ -1967,6 +1967,8 @@ __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total
   atomicAdd(total, c);
 }
 
+#include "tsc_resident.inc"
+
 // Vehicle bookkeeping per replica (conservation check K5): entered the network so far, running,
 // finished.  A vehicle inserted for the NEXT sub-step counts in none of the three.
 __global__ void k_replica_counts(DevNet N, DevState S, int *out) {

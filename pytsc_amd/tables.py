@@ -59,6 +59,7 @@ class TscConfig(C.Structure):
         ("sequential_sets", C.c_int32), ("reward_kind", C.c_int32),
         ("interval", C.c_double), ("veh_size_min_gap", C.c_double),
         ("flickering_coef", C.c_double),
+        ("kernel_family", C.c_int32), ("resident_capacity", C.c_int32),
     ]
 
 
@@ -239,6 +240,8 @@ class Tables:
             int(sim["initial_wait_time"]), int(set_offset),
             1 if sim.get("flow_rate_type", "constant") == "sequential" else 0, rk,
             interval, v_size, float(config.misc["flickering_coef"]),
+            {"auto": 0, "list": 1, "resident": 2}[str(sim.get("kernel_family", "auto"))],
+            int(sim.get("resident_capacity", 0)),
         )
         self.n_replicas = int(n_replicas)
         self.obs_size = MAX_CTRL_LANES * (int(sig["visibility"]) + LANE_STATIC) + MAX_PHASES

@@ -30,11 +30,27 @@ class VecEngine:
         self.tables = tables
         self.device = torch.device("cuda", device)
         self.R, self.A = tables.n_replicas, tables.n_agents
+        # kernel family (include/pytsc_amd.h TSC_FAMILY_*): "auto" keeps what the tables / config ask for
+        if family not in ("auto", "list", "resident"):
+            raise ValueError(f"family {family!r}: expected auto, list or resident")
+        if family != "auto":
+            tables.cfg.kernel_family = {"list": 1, "resident": 2}[family]
         h = C.c_void_p()
         _lib.check(self.lib.tsc_create(C.byref(tables.net), C.byref(tables.flows), C.byref(tables.cfg),
                                        device, C.byref(h)), "tsc_create")
         self.h = h
         self.n_actions = self.lib.tsc_n_actions(h)
+        self.family = {1: "list", 2: "resident"}[self.lib.tsc_kernel_family(h)]
+        # the dominant kernel of the family: what tsc_profile_enable brackets and bench.py prices
+        self.kernel_info = {
+            "list": dict(family="list", name="k_exec", substeps_per_launch=1, traffic_file="r02_traffic_list.json",
+                         note="dense 64-item batches of lane / lane-link work items drawn from all replicas; "
+                              "one of ~27 launches per env step"),
+            "resident": dict(family="resident", name="kr_step", substeps_per_launch=5,
+                             traffic_file="r02_traffic_resident.json",
+                             note="one workgroup per replica, state resident in LDS over the 5 sub-steps and "
+                                  "the measurement; the only launch of an env step"),
+        }[self.family]
         self.obs_size = self.lib.tsc_obs_size(h)
         self.state_size = self.lib.tsc_state_size(h)
         R, A, dev = self.R, self.A, self.device

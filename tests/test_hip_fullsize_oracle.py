@@ -57,22 +57,25 @@ def _run_linked(oracle_lib, scen, R, steps, snap_at, n_sets=8, rate=700.0, min_v
     orc.close()
 
 
-def test_4x4_r4096_linked_to_oracle(oracle_lib):
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_4x4_r4096_linked_to_oracle(family, oracle_lib):
     """BASELINE config 1 at the metric's size (4096 replicas), 100 env steps."""
-    _run_linked(oracle_lib, "syn_4x4", 4096, 100, snap_at=(50, 100), min_veh=700)
+    _run_linked(oracle_lib, "syn_4x4", 4096, 100, snap_at=(50, 100), min_veh=700, family=family)
 
 
-def test_4x4_r8192_linked_to_oracle(oracle_lib):
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_4x4_r8192_linked_to_oracle(family, oracle_lib):
     """The per-GPU shard of BASELINE config 3 (65536 replicas over 8 GPUs = 8192 each)."""
-    _run_linked(oracle_lib, "syn_4x4", 8192, 80, snap_at=(80,), min_veh=600)
+    _run_linked(oracle_lib, "syn_4x4", 8192, 80, snap_at=(80,), min_veh=600, family=family)
 
 
 def test_16x16_r256_linked_to_oracle(oracle_lib):
     """BASELINE config 2's network (256 agents) with 256 replicas: four 64-replica blocks."""
-    _run_linked(oracle_lib, "syn_16x16", 256, 80, snap_at=(80,), min_veh=2000, sim_length=900)
+    _run_linked(oracle_lib, "syn_16x16", 256, 80, snap_at=(80,), min_veh=2000, family="list", sim_length=900)
 
 
-def test_visibility_12_matches_oracle(oracle_lib):
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_visibility_12_matches_oracle(family, oracle_lib):
     """A visibility other than the default 10 (window predicate bits beyond 32: the 64-bit word
     of k_measure / k_agent), 3x3 grid, 6 replicas with different action streams."""
     import torch
@@ -87,7 +90,7 @@ def test_visibility_12_matches_oracle(oracle_lib):
         return build_tables(cfg, n_replicas=R)
 
     R = 6
-    eng, orc = VecEngine(tables(R)), oracle_lib.Oracle(tables(R))
+    eng, orc = VecEngine(tables(R), family=family), oracle_lib.Oracle(tables(R))
     assert eng.obs_size == 16 * (9 + 12) + 20
     buf, out = eng.observe(), orc.observe()
     for s in range(90):

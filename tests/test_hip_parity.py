@@ -25,15 +25,17 @@ def _cmp_outputs(buf, out, s, R):
         assert np.array_equal(g["local_reward"][r], out.local_reward[0])
 
 
+@pytest.mark.parametrize("family", ["list", "resident"])
 @pytest.mark.parametrize("case", CASES)
-def test_hip_matches_oracle_and_golden(case, oracle_lib):
+def test_hip_matches_oracle_and_golden(case, family, oracle_lib):
     from pytsc_amd.vec_env import VecEngine
 
     R = 3
     inputs, exp, ref, cfg, tables1 = load_case(case, n_replicas=1)
     _, _, _, _, tablesR = load_case(case, n_replicas=R)
     o = oracle_lib.Oracle(tables1)
-    eng = VecEngine(tablesR)
+    eng = VecEngine(tablesR, family=family)
+    assert eng.family == family
     _cmp_outputs(eng.observe(), o.observe(), -1, R)
     import torch
 

@@ -41,7 +41,8 @@ def test_16x16_grid_matches_oracle(oracle_lib):
     eng.close()
 
 
-def test_flow_sets_and_sequential_restart_match_oracle(oracle_lib):
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_flow_sets_and_sequential_restart_match_oracle(family, oracle_lib):
     """3 flow sets, sequential advance on restart (backends/cityflow/config.py:63-76),
     short simulated 'hour' so that restarts happen inside the test."""
     import torch
@@ -51,7 +52,7 @@ def test_flow_sets_and_sequential_restart_match_oracle(oracle_lib):
     kw = dict(flow_rate=800.0, n_flow_sets=3, sim_length=100, episode_limit=50,
               flow_rate_type="sequential")
     R = 5
-    eng = VecEngine(_tables("syn_2x2", R, **kw))
+    eng = VecEngine(_tables("syn_2x2", R, **kw), family=family)
     orc = oracle_lib.Oracle(_tables("syn_2x2", R, **kw))
     rng = np.random.default_rng(4)
     out = orc.observe()
@@ -78,7 +79,8 @@ def test_flow_sets_and_sequential_restart_match_oracle(oracle_lib):
     eng.close()
 
 
-def test_full_size_properties_4x4_r4096():
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_full_size_properties_4x4_r4096(family):
     """BASELINE config 1 size: replicas sharing a flow set stay bit-identical under
     identical actions (K6), vehicles are conserved (K5), no device error."""
     import torch
@@ -87,7 +89,7 @@ def test_full_size_properties_4x4_r4096():
 
     R = 4096
     eng = VecEngine(_tables("syn_4x4", R, flow_rate=700.0, n_flow_sets=4),
-                    want=("obs", "mask", "stats", "global_reward"))
+                    want=("obs", "mask", "stats", "global_reward"), family=family)
     g = torch.Generator(device="cuda")
     g.manual_seed(0)
     buf = eng.observe()
@@ -109,7 +111,8 @@ def test_full_size_properties_4x4_r4096():
     eng.close()
 
 
-def test_congested_queues_match_oracle(oracle_lib):
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_congested_queues_match_oracle(family, oracle_lib):
     """Heavy demand with long red phases: long standing queues, spill-back onto
     lane-links, discharge waves -- the states in which k_enum settles vehicles without
     arithmetic (stopped queue members, heads at a red light) and skips standing blocks.
@@ -120,7 +123,7 @@ def test_congested_queues_match_oracle(oracle_lib):
 
     kw = dict(flow_rate=1500.0, n_flow_sets=2, sim_length=900)
     R = 6
-    eng = VecEngine(_tables("syn_3x3", R, **kw))
+    eng = VecEngine(_tables("syn_3x3", R, **kw), family=family)
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
     rng = np.random.default_rng(11)
     out = orc.observe()
@@ -147,7 +150,8 @@ def test_congested_queues_match_oracle(oracle_lib):
     eng.close()
 
 
-def test_mixed_vehicle_templates_match_oracle(oracle_lib):
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_mixed_vehicle_templates_match_oracle(family, oracle_lib):
     """Three vehicle templates (car, van, slow truck) in one demand: the multi-template
     instantiations of k_enum / k_exec / k_commit (per-vehicle parameter look-ups, leader
     lengths in gaps, approach distances) under congestion, against the oracle."""
@@ -180,7 +184,7 @@ def test_mixed_vehicle_templates_match_oracle(oracle_lib):
         return build_tables(cfg, n_replicas=R)
 
     R = 4
-    eng = VecEngine(tables(R))
+    eng = VecEngine(tables(R), family=family)
     orc = oracle_lib.Oracle(tables(R))
     rng = np.random.default_rng(5)
     out = orc.observe()
@@ -237,7 +241,8 @@ def test_full_size_properties_16x16_r4096():
     eng.close()
 
 
-def test_full_size_properties_jinan_r8192():
+@pytest.mark.parametrize("family", ["list", "resident"])
+def test_full_size_properties_jinan_r8192(family):
     """BASELINE config 4 size: the Jinan 3x4 network with its real flow file, 8192 replicas
     (one flow set: every replica must stay identical to replica 0 under identical actions,
     and differ from it under different ones)."""
@@ -248,7 +253,7 @@ def test_full_size_properties_jinan_r8192():
 
     R = 8192
     _, _, _, _, tables = load_case("jinan_3_4_random", n_replicas=R)
-    eng = VecEngine(tables, want=("obs", "mask", "stats"))
+    eng = VecEngine(tables, want=("obs", "mask", "stats"), family=family)
     g = torch.Generator(device="cuda")
     g.manual_seed(1)
     buf = eng.observe()
