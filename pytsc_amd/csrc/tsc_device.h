@@ -72,34 +72,45 @@ struct CrossRec {
   int pad;
 };
 
+// Pointers inside structs that a kernel reads through a pointer (RParams of the resident family) carry the
+// global address space in device code: a pointer loaded from memory would otherwise be generic and every access
+// through it a flat_* instruction.  Host code sees plain pointers of the same size.
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define TSC_G __attribute__((address_space(1)))
+#else
+#define TSC_G
+#endif
+template <typename T>
+using GP = const T TSC_G *; // read-only table in global memory
+
 struct DevNet {
   int n_lanes, n_links, n_drv, n_agents, n_routes, n_tmpl, single_tmpl;
   int max_links_per_agent;
-  const double *drv_length, *drv_max_speed;
-  const int *drv_cap, *drv_slot_base;
-  const int *lane_out_ptr, *lane_out_links, *lane_in_ptr, *lane_in_links;
-  const double *lane_len_pytsc;
-  const int *lane_bins, *lane_static;
-  const int *lane_is_entry; // 1: some flow set spawns vehicles on this lane
-  const int *link_start_lane, *link_end_lane, *link_type, *link_agent, *link_local;
-  const uint32_t *link_avail_mask;
-  const unsigned long long *link_conflict; // local-index mask of links crossing this link
-  const unsigned long long *agent_phase_avail; // [n_agents*32]: local-index mask of links available in raw phase p
-  const int *link_cross_ptr, *cross_other, *cross_peer; // cross_peer: entry of the same cross in the other link's list
-  const double *cross_dist_self, *cross_dist_other;
-  const CrossRec *cross_rec; // [n_cross + 4], padded for the software-pipelined scan
-  const int *agent_link_ptr, *agent_links; // CSR: links of an agent in local order
-  const int *agent_n_phases, *agent_phase_raw, *agent_phase_green, *agent_phase_min, *agent_phase_max;
-  const int *agent_inc_ptr, *agent_inc_lanes, *agent_out_ptr, *agent_out_lanes;
-  const int *agent_nbr_ptr, *agent_nbr;
-  const double *agent_nbr_w;
-  const int *route_ptr, *route_drv;
-  const int2 *veh_rrange; // per vehicle (all flow sets): [begin, end) of its route in route_drv
-  const double *tmpl;
+  GP<double> drv_length, drv_max_speed;
+  GP<int> drv_cap, drv_slot_base;
+  GP<int> lane_out_ptr, lane_out_links, lane_in_ptr, lane_in_links;
+  GP<double> lane_len_pytsc;
+  GP<int> lane_bins, lane_static;
+  GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane
+  GP<int> link_start_lane, link_end_lane, link_type, link_agent, link_local;
+  GP<uint32_t> link_avail_mask;
+  GP<unsigned long long> link_conflict; // local-index mask of links crossing this link
+  GP<unsigned long long> agent_phase_avail; // [n_agents*32]: local-index mask of links available in raw phase p
+  GP<int> link_cross_ptr, cross_other, cross_peer; // cross_peer: entry of the same cross in the other link's list
+  GP<double> cross_dist_self, cross_dist_other;
+  GP<CrossRec> cross_rec; // [n_cross + 4], padded for the software-pipelined scan
+  GP<int> agent_link_ptr, agent_links; // CSR: links of an agent in local order
+  GP<int> agent_n_phases, agent_phase_raw, agent_phase_green, agent_phase_min, agent_phase_max;
+  GP<int> agent_inc_ptr, agent_inc_lanes, agent_out_ptr, agent_out_lanes;
+  GP<int> agent_nbr_ptr, agent_nbr;
+  GP<double> agent_nbr_w;
+  GP<int> route_ptr, route_drv;
+  GP<int2> veh_rrange; // per vehicle (all flow sets): [begin, end) of its route in route_drv
+  GP<double> tmpl;
   // flows
   int n_sets, sim_len;
-  const int *set_veh_ptr, *veh_route, *veh_start, *veh_tmpl, *spawn_ptr, *spawn_vid, *created_cnt;
-  const long long *created_tsum;
+  GP<int> set_veh_ptr, veh_route, veh_start, veh_tmpl, spawn_ptr, spawn_vid, created_cnt;
+  GP<long long> created_tsum;
 };
 
 struct DevState {

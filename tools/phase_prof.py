@@ -76,6 +76,10 @@ def main():
         per = out[i] / (R * args.steps)
         print(f"{name:10s} {per:12.0f} cycles/workgroup/env-step  {100.0 * out[i] / tot:5.1f} %")
     print(f"{'total':10s} {tot / (R * args.steps):12.0f}")
+    n = R * args.steps
+    print(f"exec, per wave per env step: heavy chunks {out[11] / n / 16:.0f} cycles, follower chunks {out[12] / n / 16:.0f} "
+          f"(16 waves; the phase lasts until the slowest wave is done)")
+    print(f"items per sub-step: heavy {out[13] / n / 5:.1f}, followers {out[14] / n / 5:.1f}, cross candidates {out[15] / n / 5:.1f}")
 
 
 if __name__ == "__main__":
