@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rows", type=int, default=4)
     ap.add_argument("--cols", type=int, default=4)
+    ap.add_argument("--threads", type=int, default=0, help="resident family: threads per workgroup")
     ap.add_argument("--ablate", type=lambda x: int(x, 0), default=0, help="ablation bits set after the pre-roll")
     args = ap.parse_args()
     if args.build:
@@ -49,6 +50,7 @@ def main():
 
     R = args.replicas
     tables = bench.workload_tables(args.rows, args.cols, R, 0, 700.0, 8)
+    tables.cfg.resident_threads = args.threads
     eng = VecEngine(tables, device=0, want=tuple(bench.DEFAULT_OUTPUTS.split(",")), family="resident")
     A = tables.n_agents
     acts = torch.empty((R, A), device="cuda:0", dtype=torch.int32)
@@ -77,7 +79,7 @@ def main():
         print(f"{name:10s} {per:12.0f} cycles/workgroup/env-step  {100.0 * out[i] / tot:5.1f} %")
     print(f"{'total':10s} {tot / (R * args.steps):12.0f}")
     n = R * args.steps
-    print(f"exec, per wave per env step: heavy chunks {out[11] / n / 16:.0f} cycles, follower chunks {out[12] / n / 16:.0f} "
+    print(f"exec, per wave per env step: heavy chunks {out[11] / n:.0f} cycles (all waves), follower chunks {out[12] / n:.0f} "
           f"(16 waves; the phase lasts until the slowest wave is done)")
     print(f"items per sub-step: heavy {out[13] / n / 5:.1f}, followers {out[14] / n / 5:.1f}, cross candidates {out[15] / n / 5:.1f}")
 
