@@ -22,17 +22,45 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def check_no_vector_spills(report, kernel="kr_step"):
+    """The resident kernel must not spill vector registers: a spill store placed under a partial EXEC mask
+    loses the inactive lanes (seen with the 1024-thread build of round 2: a loop counter reloaded as garbage,
+    the launch never ended).  `report` is hipcc's -Rpass-analysis=kernel-resource-usage output."""
+    bad, name = [], None
+    for line in report.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif name and kernel in name and ("VGPRs Spill:" in line or "ScratchSize [bytes/lane]:" in line):
+            if int(line.split(":")[-1].split()[0]) != 0:
+                bad.append((name, line.split("remark:")[-1].strip()))
+    if bad:
+        raise RuntimeError("vector register spills in the resident kernel: %r" % bad)
+
+
+def build(force=False, verbose=False, extra=(), out=None, report=False):
+    out = out or LIB
+    if out == LIB and not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", LIB, SRC]
+    cmd = [HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + list(extra) + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0 or report:
+        print(p.stdout)
+    else:
+        for line in p.stdout.splitlines():
+            if ": warning:" in line:
+                print(line)
+    if p.returncode != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    try:
+        check_no_vector_spills(p.stdout)
+    except RuntimeError:
+        os.remove(out)
+        raise
+    return out
 
 
 if __name__ == "__main__":
-    build(force="-f" in sys.argv, verbose=True,
-          extra=["-Rpass-analysis=kernel-resource-usage"] if "-r" in sys.argv else ())
+    build(force="-f" in sys.argv, verbose=True, report="-r" in sys.argv)

@@ -19,11 +19,8 @@ PHASES = ["load", "links", "spawn0", "classify", "exec", "unlink", "append", "me
 
 def build():
     from pytsc_amd import build as b
-    import subprocess
 
-    cmd = [b.HIPCC] + b.FLAGS + ["-DTSC_DIAG", "-o", DIAG, b.SRC]
-    print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    b.build(force=True, verbose=True, extra=["-DTSC_DIAG"], out=DIAG)
 
 
 def main():
@@ -57,9 +54,9 @@ def main():
     buf = eng.observe()
     for _ in range(args.preroll):
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     eng.lib.tsc_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int32]
-    eng.lib.tsc_debug_phase_cycles(eng.h, out, 16)  # drop the pre-roll
+    eng.lib.tsc_debug_phase_cycles(eng.h, out, 32)  # drop the pre-roll
     if args.ablate:
         eng.lib.tsc_debug_set_ablate(eng.h, args.ablate)
     torch.cuda.synchronize()
@@ -70,8 +67,8 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
-    n = eng.lib.tsc_debug_phase_cycles(eng.h, out, 16)
-    assert n == 16, n
+    n = eng.lib.tsc_debug_phase_cycles(eng.h, out, 32)
+    assert n == 32, n
     tot = sum(out[i] for i in range(len(PHASES)))
     print(f"R={R} V/replica={eng.mean_vehicles():.0f} {ms:.3f} ms/env step (diag build, ablate {args.ablate:#x}), errors {eng.errors()}")
     for i, name in enumerate(PHASES):
@@ -81,6 +78,9 @@ def main():
     n = R * args.steps
     print(f"exec, per wave per env step: heavy chunks {out[11] / n:.0f} cycles (all waves), follower chunks {out[12] / n:.0f} "
           f"(16 waves; the phase lasts until the slowest wave is done)")
+    print("agent sub-phases (wave 0): sums %.0f, stats+mask %.0f, obs row build %.0f, obs row store %.0f" % tuple(out[i] / n for i in (16, 17, 18, 19)))
+    print("exec stages per env step: A + followers %.0f, B (tasks) %.0f, C (finish) %.0f" % tuple(out[i] / n for i in (20, 21, 22)))
+    print("stage A of wave 0 per env step: gathers+leader/gap %.0f, car-following %.0f, signal+candidates %.0f, task emission %.0f, finish %.0f" % tuple(out[i] / n for i in (23, 24, 25, 26, 27)))
     print(f"items per sub-step: heavy {out[13] / n / 5:.1f}, followers {out[14] / n / 5:.1f}, cross candidates {out[15] / n / 5:.1f}")
 
 
