@@ -223,7 +223,7 @@ typedef struct tsc_config {
   double flickering_coef;        /* 0.01                                          */
   int32_t kernel_family;         /* TSC_FAMILY_*: which kernel family steps the replicas */
   int32_t resident_capacity;     /* resident family: vehicle records per replica (0 = default) */
-  int32_t resident_threads;      /* resident family: threads per workgroup, 512 or 768 (0 = default: 768) */
+  int32_t resident_threads;      /* resident family: threads per workgroup: 768 (0 = default) */
   int32_t reserved0;             /* keep the struct a multiple of 8 bytes */
 } tsc_config_t;
 
