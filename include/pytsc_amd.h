@@ -331,6 +331,13 @@ int tsc_replica_counts(tsc_handle_t h, int32_t *counts_dev, void *stream);
 int tsc_profile_enable(tsc_handle_t h, int on);
 int tsc_profile_read(tsc_handle_t h, double *total_ms, int32_t *n_launches);
 
+/* Would tsc_create accept these tables, and with which kernel family?  Pure host code (no GPU needed): the
+ * create-time requirements of the HIP path and, unless cfg->kernel_family is TSC_FAMILY_LIST, whether a
+ * replica fits on chip.  Returns TSC_OK / TSC_EUNSUP / TSC_EINVAL; *family_out = the family tsc_create would pick,
+ * *resident_capacity_out = vehicle records per replica of the resident family (0 for the list family). */
+int tsc_check_tables(const tsc_net_t *net, const tsc_flows_t *flows, const tsc_config_t *cfg, int32_t *family_out,
+                     int32_t *resident_capacity_out);
+
 /* The kernel family the handle runs (TSC_FAMILY_LIST / TSC_FAMILY_RESIDENT). */
 int tsc_kernel_family(tsc_handle_t h);
 

@@ -83,11 +83,32 @@ def _argmax_random_ties(score, allow, generator=None):
     return (u * tie).argmax(-1)
 
 
+def queue_scores(ctx, counts):
+    """[R, A, P]: stopped vehicles (bins == 0.0) in the incoming windows of each phase's lanes
+    (GreedyController._compute_queue_for_phase, controllers.py:93-112)."""
+    return torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 0].float())
+
+
+def pressure_scores(ctx, counts):
+    """[R, A, P]: MaxPressureController._compute_pressure_for_phase (controllers.py:153-178), including its
+    quirk that only the LAST outgoing lane of a movement is counted."""
+    occ_in = counts[..., 1].float()   # [R, L]
+    occ_out = counts[..., 2].float()  # [R, L]
+    R = occ_in.shape[0]
+    out_sel = occ_out[:, ctx.phase_last_out]  # [R, A, P, L]
+    return ((occ_in.view(R, 1, 1, -1) - out_sel).abs() * ctx.phase_inc.unsqueeze(0)).sum(-1)
+
+
+def flow_scores(ctx, counts):
+    """[R, A, P]: vehicles (bins >= 0) in the incoming windows of each phase's lanes
+    (SOTLController._compute_flow_for_phase, controllers.py:227-242)."""
+    return torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 1].float())
+
+
 def greedy(ctx, buf, counts, generator=None):
     """GreedyController (controllers.py:69-112): most stopped vehicles in the window."""
     cur, _ = ctx.phase_state(buf)
-    zero = counts[..., 0].float()  # [R, L]
-    score = torch.einsum("apl,rl->rap", ctx.phase_inc, zero)
+    score = queue_scores(ctx, counts)
     allow = ctx.allowable(buf)
     pick = _argmax_random_ties(score, allow, generator)
     is_green = ctx.green.unsqueeze(0).expand(cur.shape[0], -1, -1).gather(2, cur.unsqueeze(-1)).squeeze(-1)
@@ -98,12 +119,8 @@ def greedy(ctx, buf, counts, generator=None):
 def max_pressure(ctx, buf, counts, generator=None):
     """MaxPressureController (controllers.py:127-178)."""
     cur, _ = ctx.phase_state(buf)
-    occ_in = counts[..., 1].float()   # [R, L]
-    occ_out = counts[..., 2].float()  # [R, L]
-    R = occ_in.shape[0]
-    out_sel = occ_out[:, ctx.phase_last_out]  # [R, A, P, L]
-    press = (occ_in.view(R, 1, 1, -1) - out_sel).abs() * ctx.phase_inc.unsqueeze(0)
-    score = press.sum(-1)
+    R = cur.shape[0]
+    score = pressure_scores(ctx, counts)
     allow = ctx.allowable(buf)
     pick = _argmax_random_ties(score, allow, generator)
     is_green = ctx.green.unsqueeze(0).expand(R, -1, -1).gather(2, cur.unsqueeze(-1)).squeeze(-1)
@@ -115,7 +132,7 @@ def sotl(ctx, buf, counts, theta=3, mu=4, phi_min=5):
     """SOTLController (controllers.py:200-242)."""
     cur, top = ctx.phase_state(buf)
     R = cur.shape[0]
-    flow = torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 1].float())
+    flow = flow_scores(ctx, counts)
     nxt = (cur + 1) % ctx.n_phases.view(1, -1)
     nxt_green = (cur + 2) % ctx.n_phases.view(1, -1)
     allow = ctx.allowable(buf)

@@ -77,6 +77,32 @@ CASES = {
         signal={"action_space": "phase_selection", "round_robin": False},
         policy="random",
     ),
+    # ---- "next" rows: the reference's rule-based controllers drive the env
+    # (pytsc/controllers/controllers.py:57-242); every step also records, for every signal and phase, the
+    # allowable-switch flags and the three scores the controllers rank phases by (stopped vehicles, pressure,
+    # flow), the optional per-agent / per-lane info keys, and every 6th step density_map and its max spanning tree
+    # (backends/cityflow/metrics.py:170-260); the EPyMARL wrapper's step / reset tuples (wrappers/epymarl.py:93-111).
+    "syn_2x2_ctrl_sotl": dict(
+        roadnet=("grid", 2, 2), flows=("poisson", 800.0, 5), steps=120,
+        signal={"action_space": "phase_selection", "round_robin": False},
+        misc={"return_agent_stats": True, "return_lane_stats": True},
+        policy="sotl", extras=True,
+    ),
+    "syn_2x2_ctrl_greedy": dict(
+        roadnet=("grid", 2, 2), flows=("poisson", 800.0, 6), steps=100,
+        signal={"action_space": "phase_selection", "round_robin": False},
+        policy="greedy", extras=True,
+    ),
+    "syn_1x3_ctrl_max_pressure": dict(
+        roadnet=("grid", 1, 3), flows=("poisson", 800.0, 7), steps=100,
+        signal={"action_space": "phase_selection", "round_robin": False},
+        policy="max_pressure", extras=True,
+    ),
+    "syn_2x2_epymarl": dict(
+        roadnet=("grid", 2, 2), flows=("poisson", 700.0, 8), steps=80,
+        signal={"action_space": "phase_selection", "round_robin": False},
+        policy="random", wrapper="epymarl",
+    ),
 }
 
 
@@ -127,16 +153,54 @@ def generate(name):
     common_config.CONFIG_DIR = root
     cf_config.CONFIG_DIR = os.path.join(root, "cityflow")
     from pytsc import TrafficSignalNetwork
+    from pytsc.controllers import controllers as ref_ctrl
     from pytsc.controllers.controllers import FixedTimeController
 
     random.seed(0)
     np.random.seed(0)
-    env = TrafficSignalNetwork(name, "cityflow")
+    wrap = None
+    if case.get("wrapper") == "epymarl":
+        from pytsc.wrappers.epymarl import EPyMARLTrafficSignalNetwork
+
+        wrap = EPyMARLTrafficSignalNetwork(map_name=name, simulator_backend="cityflow")
+        env = wrap.tsc_env
+    else:
+        env = TrafficSignalNetwork(name, "cityflow")
     A = env.n_agents
     lanes = env.parsed_network.lanes
     ts_list = list(env.traffic_signals.values())
     controllers = [FixedTimeController(ts) for ts in ts_list]
+    drivers = {"sotl": ref_ctrl.SOTLController, "greedy": ref_ctrl.GreedyController,
+               "max_pressure": ref_ctrl.MaxPressureController}
+    if case["policy"] in drivers:
+        controllers = [drivers[case["policy"]](ts) for ts in ts_list]
+    score_ctrl = [(ref_ctrl.GreedyController(ts), ref_ctrl.MaxPressureController(ts), ref_ctrl.SOTLController(ts))
+                  for ts in ts_list]
+    P_max = max(ts.controller.n_phases if hasattr(ts.controller, "n_phases") else len(ts.config["phases"]) for ts in ts_list)
+    extras = {k: [] for k in ("allow", "score_queue", "score_pressure", "score_flow", "dm_steps", "density_map", "mst",
+                              "opt_agent", "opt_lane", "wrap_reward", "wrap_done", "wrap_reset_obs")}
+    opt_agent_keys = ("phase", "n_queued", "mean_speed", "mean_delay", "density", "pressure")
+    opt_lane_keys = ("n_vehicles", "n_queued", "mean_speed", "occupancy")
     rng = np.random.default_rng(12345)
+
+    def record_scores():
+        inp = env.simulator.step_measurements
+        al = np.zeros((A, P_max), np.int8)
+        sq = np.zeros((A, P_max), np.float64)
+        sp = np.zeros((A, P_max), np.float64)
+        sf = np.zeros((A, P_max), np.float64)
+        for a, ts in enumerate(ts_list):
+            n_ph = len(ts.config["phases"])
+            al[a, :n_ph] = ts.controller.get_allowable_phase_switches()
+            g, m, so = score_ctrl[a]
+            for k in range(n_ph):
+                sq[a, k] = g._compute_queue_for_phase(inp, k)
+                sp[a, k] = m._compute_pressure_for_phase(inp, k)
+                sf[a, k] = so._compute_flow_for_phase(inp, k)
+        extras["allow"].append(al)
+        extras["score_queue"].append(sq)
+        extras["score_pressure"].append(sp)
+        extras["score_flow"].append(sf)
 
     def lane_arrays():
         lm = env.simulator.step_measurements["lane"]
@@ -171,11 +235,31 @@ def generate(name):
                  "density", "pressure", "network_flow")
     for s in range(case["steps"]):
         mask = env.get_action_mask()
+        if case.get("extras"):
+            record_scores()
         if case["policy"] == "fixed_time":
             acts = [int(c.get_action(None)) for c in controllers]
+        elif case["policy"] in drivers:
+            acts = [int(c.get_action(env.simulator.step_measurements)) for c in controllers]
         else:
             acts = [int(rng.choice(np.nonzero(np.asarray(mask[a]))[0])) for a in range(A)]
-        greward, done, info = env.step(acts)
+        if wrap is not None:
+            w_obs, w_rew, done, w_trunc, info = wrap.step(acts)
+            assert w_trunc is False and w_obs == env.get_observations()
+            greward = w_rew * A  # (common_reward / mean scalarisation: wrappers/epymarl.py:104-111)
+            extras["wrap_reward"].append(float(w_rew))
+            extras["wrap_done"].append(bool(done))
+        else:
+            greward, done, info = env.step(acts)
+        if case.get("extras"):
+            if env.config.misc["return_agent_stats"]:
+                extras["opt_agent"].append([[float(info[f"{ts.id}__{k}"]) for k in opt_agent_keys] for ts in ts_list])
+            if env.config.misc["return_lane_stats"]:
+                extras["opt_lane"].append([[float(info[f"{l}__{k}"]) for k in opt_lane_keys] for l in lanes])
+            if s % 6 == 0:
+                extras["dm_steps"].append(s)
+                extras["density_map"].append(np.asarray(env.metrics.density_map, np.float64))
+                extras["mst"].append(np.asarray(env.metrics.mst, np.float64))
         rec["actions"].append(acts)
         rec["obs"].append(env.get_observations())
         rec["state"].append(env.get_state())
@@ -197,7 +281,11 @@ def generate(name):
             pm_steps.append(s)
             pm_vals.append(posmats())
         if done:
-            env.restart()
+            if wrap is not None:
+                r_obs, r_state = wrap.reset()
+                extras["wrap_reset_obs"].append(np.asarray(r_obs, np.float64).astype(np.int8))
+            else:
+                env.restart()
     out_dir = os.path.join(HERE, name)
     os.makedirs(out_dir, exist_ok=True)
     inputs = {
@@ -232,6 +320,7 @@ def generate(name):
         lane_occ=np.asarray(rec["lane_occ"], np.float64),
         agent_stats=np.asarray(rec["agent_stats"], np.float64),
         posmat_steps=np.asarray(pm_steps, np.int32), posmat=pm_arr,
+        **{"x_" + k: np.asarray(v) for k, v in extras.items() if len(v)},
     )
     pn = env.parsed_network
     parser = {
