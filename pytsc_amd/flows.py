@@ -108,10 +108,14 @@ def route_to_drivables(rn, roads):
 class FlowSet:
     """One demand file expanded to vehicles, sorted in creation order."""
 
-    def __init__(self, veh_route, veh_start, veh_tmpl):
+    def __init__(self, veh_route, veh_start, veh_tmpl, veh_entry=None, veh_k=None):
         self.veh_route = np.asarray(veh_route, dtype=np.int32)
         self.veh_start = np.asarray(veh_start, dtype=np.int32)
         self.veh_tmpl = np.asarray(veh_tmpl, dtype=np.int32)
+        # host side only: the flow entry a vehicle came from and its number within it -- CityFlow names vehicles
+        # flow_<entry>_<k>, the tables number them in creation order
+        self.veh_entry = None if veh_entry is None else np.asarray(veh_entry, dtype=np.int32)
+        self.veh_k = None if veh_k is None else np.asarray(veh_k, dtype=np.int32)
 
     @property
     def n_veh(self):
@@ -189,7 +193,8 @@ class FlowCompiler:
                 s += 1
         per_step.sort(key=lambda t: (t[0], t[1], t[2]))
         fs = FlowSet(
-            [t[3] for t in per_step], [t[0] for t in per_step], [t[4] for t in per_step]
+            [t[3] for t in per_step], [t[0] for t in per_step], [t[4] for t in per_step],
+            [t[1] for t in per_step], [t[2] for t in per_step],
         )
         self.sets.append(fs)
         return fs

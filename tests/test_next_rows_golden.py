@@ -216,20 +216,18 @@ def test_vec_epymarl_wrapper_matches_reference_tuples():
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["list", "resident"])
 def test_trip_generator_file_runs_on_hip_like_the_oracle(family, tmp_path, oracle_lib):
-    """A flow file written by the restated interval (Weibull-profile) generator -- the recipe of BASELINE config 0,
-    tests/golden/trips pins its trips against the reference's generator -- read back from disk, compiled and
-    stepped for 60 env steps: HIP == oracle, bit for bit."""
+    """A flow file written by the restated Gaussian inter-arrival generator (tests/golden/trips pins its trips
+    against the reference's generator), read back from disk, compiled and stepped for 60 env steps: HIP == oracle,
+    bit for bit."""
     import pytsc_amd.trip_generator as tg
     from pytsc_amd.config import Config
     from pytsc_amd.flows import load_flow_file
     from pytsc_amd.scenario import build_tables
     from pytsc_amd.vec_env import VecEngine
 
-    # max rate 700 veh/h per entry road (inter-arrival 3600/700 s), sigma 0.8: the recipe of the reference's
-    # tests/test_cityflow_weibull_flow_generation.py:8-30
-    gen = tg.IntervalCityFlowTripGenerator("syn_2x2", 0, 720, 3600 / 700, 0.8, seed=0)
-    path = gen.generate_flows(str(tmp_path), 1, interval_duration=360)
-    assert os.path.basename(path).startswith("1__syn_2x2__interval_")
+    gen = tg.CityFlowTripGenerator("syn_2x2", 0, 720, 5.0, 0.8, seed=0)
+    path = gen.generate_flows(str(tmp_path))
+    assert os.path.basename(path) == "syn_2x2__gaussian_144_flows.json"
     entries = load_flow_file(path)
     assert len(entries) > 300
 
