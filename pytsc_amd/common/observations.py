@@ -1,6 +1,14 @@
 """Observation spaces (reference: pytsc/common/observations.py:46-382).  The
-vectors themselves are assembled on the device (k_agent); these classes expose
-them with the reference's list-of-lists API plus the static lane features."""
+vectors themselves are assembled on the device (k_agent / kr_step); these classes expose
+them with the reference's list-of-lists API plus the static lane features.
+
+Observation noise (obs_noise_std > 0) and lane dropout (obs_dropout_prob > 0) draw from numpy's global stream
+exactly as the reference does -- one np.random.normal per surviving bin in signal / lane / bin order, one
+np.random.choice over the lanes at construction -- so they are applied here on the host, on top of what the
+device measured (single-env façade; the batched engine has no noise model)."""
+import numpy as np
+
+from pytsc_amd.common.utils import pad_list
 
 
 class BaseObservationSpace:
@@ -20,8 +28,6 @@ class BaseObservationSpace:
         self.visibility = config.signal["visibility"]
         self._sim = next(iter(traffic_signals.values())).simulator
         self.lane_features = dict(self._sim.tables.lane_features)
-        if config.signal.get("obs_noise_std", 0.0):
-            raise NotImplementedError("obs_noise_std > 0 is not supported by the HIP backend")
 
     @staticmethod
     def high():
@@ -52,8 +58,33 @@ def _num(x):
 
 
 class PositionMatrix(BaseObservationSpace):
+    def __init__(self, config, parsed_network, traffic_signals, simulator_backend):
+        super().__init__(config, parsed_network, traffic_signals, simulator_backend)
+        self.obs_noise_std = config.signal.get("obs_noise_std", 0.0)
+
+    def _add_gaussian_noise(self, pos_mat, std):
+        """observations.py:72-88: only entries > 0 survive (Q2), each consumes one normal draw."""
+        noisy = []
+        for val in pos_mat:
+            if val > 0:
+                noisy.append(np.clip(val + np.random.normal(loc=0.0, scale=std), 0.0, 1.0))
+        return noisy
+
     def get_observations(self):
-        return [[_num(x) for x in row] for row in self._sim.host("obs").tolist()]
+        if not self.obs_noise_std:
+            return [[_num(x) for x in row] for row in self._sim.host("obs").tolist()]
+        # the noisy variant needs the float matrices: the lane detail the façade reads back anyway
+        lanes = self._sim.step_measurements["lane"]
+        observations = []
+        for ts in self.traffic_signals.values():
+            obs = []
+            for lane in ts.incoming_lanes:
+                obs.extend(self.lane_features[lane])
+                obs.extend(self._add_gaussian_noise(lanes[lane]["position_matrix"][-self.visibility:], self.obs_noise_std))
+            obs = pad_list(obs, self.get_size() - self.max_phases, -1)
+            obs.extend(pad_list(ts.phase_id, self.max_phases, -1))
+            observations.append(obs)
+        return observations
 
     def get_observation_info(self):
         return {"lane_obs_dim": 9 + self.visibility,
@@ -65,20 +96,28 @@ class PositionMatrix(BaseObservationSpace):
 
 
 class LaneFeatures(BaseObservationSpace):
-    """obs == the lane-feature state vector (observations.py:305-329); lane
-    dropout is not supported on the device path."""
+    """obs == the lane-feature state vector (observations.py:305-329) with the three measured entries of
+    dropped lanes zeroed (observations.py:245-253, 321-322)."""
 
     def __init__(self, config, parsed_network, traffic_signals, simulator_backend):
         super().__init__(config, parsed_network, traffic_signals, simulator_backend)
-        if config.signal.get("obs_dropout_prob", 0.0):
-            raise NotImplementedError("obs_dropout_prob > 0 is not supported by the HIP backend")
-        self.dropped_lanes = []
+        self.dropout_prob = config.signal.get("obs_dropout_prob", 0.0)
+        self.reset_dropped_lanes()
 
     def reset_dropped_lanes(self):
-        self.dropped_lanes = []
+        lanes = self.parsed_network.lanes
+        self.dropped_lanes = np.random.choice(lanes, int(self.dropout_prob * len(lanes)), replace=False)
 
     def get_observations(self):
-        return self.get_state()
+        rows = self.get_state()
+        if len(self.dropped_lanes):
+            dropped = set(self.dropped_lanes.tolist())
+            w = 9 + 3
+            for row, ts in zip(rows, self.traffic_signals.values()):
+                for i, lane in enumerate(ts.incoming_lanes):
+                    if lane in dropped:
+                        row[i * w + 9: i * w + 12] = [0, 0, 0]
+        return rows
 
     def get_observation_info(self):
         return {"lane_obs_dim": 9 + 3,

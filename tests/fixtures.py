@@ -11,8 +11,10 @@ from pytsc_amd.grid import generate_grid
 from pytsc_amd.scenario import build_tables
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# fixtures whose observations carry host-side randomness (numpy stream): façade tests only
+HOST_ONLY_CASES = ("syn_2x2_lane_dropout", "syn_2x2_obs_noise")
 CASES = sorted(
-    d for d in os.listdir(GOLDEN) if os.path.exists(os.path.join(GOLDEN, d, "expected.npz"))
+    d for d in os.listdir(GOLDEN) if os.path.exists(os.path.join(GOLDEN, d, "expected.npz")) and d not in HOST_ONLY_CASES
 )
 
 

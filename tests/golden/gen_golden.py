@@ -98,6 +98,18 @@ CASES = {
         signal={"action_space": "phase_selection", "round_robin": False},
         policy="max_pressure", extras=True,
     ),
+    # N4: observation noise (numpy stream parity: one normal draw per surviving bin) and LaneFeatures lane dropout
+    "syn_2x2_obs_noise": dict(
+        roadnet=("grid", 2, 2), flows=("poisson", 700.0, 9), steps=60,
+        signal={"action_space": "phase_selection", "round_robin": False, "obs_noise_std": 0.35},
+        policy="random",
+    ),
+    "syn_2x2_lane_dropout": dict(
+        roadnet=("grid", 2, 2), flows=("poisson", 700.0, 10), steps=60,
+        signal={"action_space": "phase_selection", "round_robin": False, "observation_space": "lane_features",
+                "obs_dropout_prob": 0.25},
+        policy="random",
+    ),
     "syn_2x2_epymarl": dict(
         roadnet=("grid", 2, 2), flows=("poisson", 700.0, 8), steps=80,
         signal={"action_space": "phase_selection", "round_robin": False},
