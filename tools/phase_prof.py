@@ -81,7 +81,7 @@ def main():
     print("agent sub-phases (wave 0): sums %.0f, stats+mask %.0f, obs row build %.0f, obs row store %.0f" % tuple(out[i] / n for i in (16, 17, 18, 19)))
     print("stats sums (one wave): %.0f; wave 5 waits at the agent barrier: %.0f" % (out[28] / n, (out[30] - out[29]) / n))
     print("exec stages per env step: A + followers %.0f, B (tasks) %.0f, C (finish) %.0f" % tuple(out[i] / n for i in (20, 21, 22)))
-    print("stage A of wave 0 per env step: gathers+leader/gap %.0f, car-following %.0f, signal+candidates %.0f, task emission %.0f, finish %.0f" % tuple(out[i] / n for i in (23, 24, 25, 26, 27)))
+    print("stage A, first heavy chunk, per env step: half A1 (leader/gap + car-following) %.0f, half A2 (signal + tasks) %.0f" % (out[23] / n, out[24] / n))
     print(f"items per sub-step: heavy {out[13] / n / 5:.1f}, followers {out[14] / n / 5:.1f}, cross candidates {out[15] / n / 5:.1f}")
 
 
