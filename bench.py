@@ -298,9 +298,12 @@ def worker(args):
         tpath = os.path.join(REPO, "profiles", kinfo.get("traffic_file", "none"))
         if k_n and os.path.exists(tpath):
             with open(tpath) as f:
-                tj = json.load(f)
-            if (tj.get("replicas") == R and tj.get("V_a") and abs(va - tj["V_a"]) <= 0.10 * tj["V_a"]
-                    and tj.get("kernel") == kinfo.get("name")):
+                tjs = json.load(f)
+            tjs = tjs if isinstance(tjs, list) else [tjs]
+            # the record taken in the state closest to this run's
+            tjs = [t for t in tjs if t.get("replicas") == R and t.get("V_a") and t.get("kernel") == kinfo.get("name")]
+            tj = min(tjs, key=lambda t: abs(va - t["V_a"])) if tjs else {}
+            if tj and abs(va - tj["V_a"]) <= 0.10 * tj["V_a"]:
                 traffic = tj["bytes_per_launch"] / avg_launch_s / 1e9
                 traffic_src = f"profiles/{kinfo['traffic_file']}: {tj.get('formula', '')} at V_a {tj['V_a']:.1f}"
                 if traffic > HBM_PEAK_GBS:  # cannot be: the counters over-count this access pattern

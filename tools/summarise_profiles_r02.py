@@ -60,22 +60,29 @@ def main():
                 100 * allc.get("SQ_WAIT_ANY", 0) / w, 100 * allc.get("SQ_WAIT_INST_ANY", 0) / w, 100 * allc.get("SQ_ACTIVE_INST_ANY", 0) / w))
         if "TCC_HIT_sum" in allc:
             o.write("L2 hit rate %.1f %%\n" % (100 * allc["TCC_HIT_sum"] / (allc["TCC_HIT_sum"] + allc["TCC_MISS_sum"])))
-    bl = bench_line("fetch")
-    if bl and "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
+    recs = []
+    for tag_f, tag_w, last in (("fetch", "write", 20), ("fetch240", "write240", 240)):
+        bl = bench_line(tag_f) if os.path.exists(os.path.join(G, f"r02_pmc_{tag_f}.log")) else None
+        cf, cw = counters(tag_f, last), counters(tag_w, last)
+        if not (bl and "FETCH_SIZE" in cf and "WRITE_SIZE" in cw):
+            continue
         # FETCH_SIZE / WRITE_SIZE are in kilobytes; gfx950 tallies 128-byte read requests at 64 bytes: doubled
-        fetch_b, write_b = allc["FETCH_SIZE"] * 1024.0, allc["WRITE_SIZE"] * 1024.0
+        fetch_b, write_b = cf["FETCH_SIZE"] * 1024.0, cw["WRITE_SIZE"] * 1024.0
         rec = {"kernel": "kr_step", "replicas": bl["config"]["replicas_per_gpu"], "V_a": bl["config"]["V_a"],
-               "fetch_size_kb_per_launch": allc["FETCH_SIZE"], "write_size_kb_per_launch": allc["WRITE_SIZE"],
+               "command": f"bench.py --no-cpu-baseline --family resident --steps {bl['steps']} --warmup {bl['warmup']}",
+               "fetch_size_kb_per_launch": cf["FETCH_SIZE"], "write_size_kb_per_launch": cw["WRITE_SIZE"],
                "bytes_per_launch": 2.0 * fetch_b + write_b,
                "algorithmic_bytes_per_launch": bl["roofline"]["bytes_per_agent_env_step"] * bl["config"]["replicas_per_gpu"] * bl["config"]["agents"],
-               "formula": "2 x FETCH_SIZE + WRITE_SIZE (kB x 1024), mean of the last 20 launches",
+               "formula": f"2 x FETCH_SIZE + WRITE_SIZE (kB x 1024), mean of the last {last} launches",
                "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace-only passes (tools/collect_profiles_r02.sh); "
                       "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes: MI355X_MICROARCH.md, HBM); "
                       "Infinity-Cache hits are included in both counters"}
         rec["ratio_to_algorithmic"] = rec["bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+        recs.append(rec)
+    if recs:
         with open(os.path.join(P, "r02_traffic_resident.json"), "w") as o:
-            json.dump(rec, o, indent=1)
-        print(json.dumps(rec, indent=1))
+            json.dump(recs, o, indent=1)
+        print(json.dumps(recs, indent=1))
     src = os.path.join(G, "r02_bench_line.json")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "r02_bench_line.json"))
