@@ -1969,6 +1969,16 @@ __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total
 
 #include "tsc_resident.inc"
 
+// Action log of a handle that may migrate from the resident to the list family (tsc_api.inc): one byte per action.
+__global__ void k_log_actions(signed char *dst, const int *src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (signed char)src[i];
+}
+__global__ void k_unlog_actions(int *dst, const signed char *src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (int)src[i];
+}
+
 // Vehicle bookkeeping per replica (conservation check K5): entered the network so far, running,
 // finished.  A vehicle inserted for the NEXT sub-step counts in none of the three.
 __global__ void k_replica_counts(DevNet N, DevState S, int *out) {

@@ -269,3 +269,48 @@ def test_full_size_properties_jinan_r8192(family):
     assert not torch.equal(buf["stats"][0], buf["stats"][1])
     assert eng.mean_vehicles() > 100 and eng.errors() == 0
     eng.close()
+
+
+def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_lib):
+    """kernel_family AUTO: when a replica of the resident family comes within 256 vehicle records of its capacity the
+    handle moves itself to the list family by replaying its logged resets / actions (deterministic engine), and
+    carries on there.  Heavy demand on a 3x3 grid with the smallest capacity the layout allows (1472 records), partial restarts in between:
+    every step before, across and after the migration equals the oracle, and no device error is ever raised."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(flow_rate=1500.0, n_flow_sets=2, sim_length=900, episode_limit=40)
+    R = 6
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=640, **kw), family="auto")
+    assert eng.family == "resident"
+    orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
+    rng = np.random.default_rng(21)
+    out = orc.observe()
+    buf = eng.observe()
+    migrated_at = None
+    for s in range(170):
+        m = out.mask
+        acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        out = orc.step(acts)
+        buf = eng.step(torch.tensor(acts, device="cuda"))
+        assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+        assert np.array_equal(buf["stats"].cpu().numpy(), out.stats), s
+        assert np.array_equal(buf["local_reward64"].cpu().numpy(), out.local_reward64), s
+        if migrated_at is None and eng.lib.tsc_kernel_family(eng.h) == 1:
+            migrated_at = s
+        if s == 25:  # a partial restart of two replicas while still resident: replayed by the migration
+            mask = np.zeros(R, np.uint8)
+            mask[[1, 4]] = 1
+            orc.reset(mask)
+            eng.reset(torch.tensor(mask, device="cuda"))
+            out = orc.observe()
+            buf = eng.observe()
+            assert np.array_equal(buf["obs"].cpu().numpy(), out.obs)
+    assert migrated_at is not None and 25 < migrated_at < 160, migrated_at
+    for r in range(R):
+        a, b = orc.snapshot(r), eng.snapshot(r)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), r
+    assert max(len(orc.snapshot(r)[0]) for r in range(R)) > 1100  # the run did need the room
+    assert eng.errors() == 0 and orc.errors() == 0
+    eng.close()
