@@ -94,7 +94,10 @@ extern "C" {
  *             sub-steps and the measurement, ONE launch per env step; networks whose replica fits
  *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the
  *             tables do not fit it.
- *   AUTO      RESIDENT where it fits, else LIST. */
+ *   AUTO      RESIDENT where it fits, else LIST.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
+ *             logs resets / actions on the device: when a replica comes within 256 vehicle records of its capacity the
+ *             handle moves to LIST by replaying the log (same results) -- it never overflows.  A handle forced to
+ *             RESIDENT has no stand-by: a spawn that finds no free record raises the error counter (tsc_errors). */
 #define TSC_FAMILY_AUTO 0
 #define TSC_FAMILY_LIST 1
 #define TSC_FAMILY_RESIDENT 2

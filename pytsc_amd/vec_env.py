@@ -40,9 +40,8 @@ class VecEngine:
                                        device, C.byref(h)), "tsc_create")
         self.h = h
         self.n_actions = self.lib.tsc_n_actions(h)
-        self.family = {1: "list", 2: "resident"}[self.lib.tsc_kernel_family(h)]
         # the dominant kernel of the family: what tsc_profile_enable brackets and bench.py prices
-        self.kernel_info = {
+        self._kernel_infos = {
             "list": dict(family="list", name="k_exec", substeps_per_launch=1, traffic_file="r02_traffic_list.json",
                          note="dense 64-item batches of lane / lane-link work items drawn from all replicas; "
                               "one of ~27 launches per env step"),
@@ -50,7 +49,7 @@ class VecEngine:
                              traffic_file="r02_traffic_resident.json",
                              note="one workgroup per replica, state resident in LDS over the 5 sub-steps and "
                                   "the measurement; the only launch of an env step"),
-        }[self.family]
+        }
         self.obs_size = self.lib.tsc_obs_size(h)
         self.state_size = self.lib.tsc_state_size(h)
         R, A, dev = self.R, self.A, self.device
@@ -75,6 +74,16 @@ class VecEngine:
                               ptr("global_reward"), ptr("done"), ptr("terminated"), ptr("stats"),
                               ptr("agent_stats"), ptr("phase"), ptr("local_reward64"),
                               ptr("global_reward64"))
+
+    @property
+    def family(self):
+        """The kernel family the handle runs NOW: an `auto` handle that started resident moves to the list family when a
+        replica comes close to its record capacity (include/pytsc_amd.h, TSC_FAMILY_*)."""
+        return {1: "list", 2: "resident"}[self.lib.tsc_kernel_family(self.h)]
+
+    @property
+    def kernel_info(self):
+        return self._kernel_infos[self.family]
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
