@@ -19,66 +19,71 @@ SIMULATOR_MODULES = {"hip": HIP_MODULES, "cityflow": HIP_MODULES}
 
 
 class TrafficSignalNetwork:
+    """Façade over one scenario (reference: pytsc/__init__.py:28-182): same constructor,
+    getters, `step(actions) -> (reward, done, info)` and `restart()`."""
+
     def __init__(self, scenario, simulator_backend="hip", **kwargs):
-        self.scenario = scenario
-        self.simulator_backend = simulator_backend
-        assert (
-            self.simulator_backend in SUPPORTED_SIMULATOR_BACKENDS
-        ), f"Simulator backend {self.simulator_backend} not supported."
+        if simulator_backend not in SUPPORTED_SIMULATOR_BACKENDS:
+            raise AssertionError(f"Simulator backend {simulator_backend} not supported.")
         if kwargs.get("disrupted", False):
             raise NotImplementedError("disrupted (domain-randomised) configs are out of scope")
-        engine_factory = kwargs.pop("engine_factory", None)
-        modules = SIMULATOR_MODULES[simulator_backend]
-        self.config = modules["config"](scenario, **kwargs)
+        factory = kwargs.pop("engine_factory", None)
+        self.scenario, self.simulator_backend = scenario, simulator_backend
+        self._mod = SIMULATOR_MODULES[simulator_backend]
+        self.config = self._mod["config"](scenario, **kwargs)
         self._validate_config()
-        self.parsed_network = modules["network_parser"](self.config)
-        self.simulator = modules["simulator"](self.parsed_network, engine_factory=engine_factory)
-        self.simulator.start_simulator()
-        self._init_traffic_signals()
-        self._init_parsers()
-        self._set_n_agents()
-        self.hour_count = 0
-        self.episode_count = 0
+        self.parsed_network = self._mod["network_parser"](self.config)
+        self.simulator = self._mod["simulator"](self.parsed_network, engine_factory=factory)
+        self.hour_count = self.episode_count = 0
+        self._boot()
+        self.n_agents = len(self.traffic_signals)
 
-    @property
-    def episode_limit(self):
-        return int(self.config.simulator["episode_limit"] / self.config.simulator["delta_time"])
-
-    @property
-    def episode_over(self):
-        if self.simulator.sim_step > 0:
-            return self.simulator.sim_step % self.config.simulator["episode_limit"] == 0
-        return False
-
+    # ---- construction ------------------------------------------------------------------
     def _validate_config(self):
-        validate_input_against_allowed(self.config.signal["action_space"], ACTION_SPACES.keys())
-        validate_input_against_allowed(self.config.signal["observation_space"], OBSERVATION_SPACES.keys())
+        sig = self.config.signal
+        validate_input_against_allowed(sig["action_space"], ACTION_SPACES.keys())
+        validate_input_against_allowed(sig["observation_space"], OBSERVATION_SPACES.keys())
         if self.config.network["control_scheme"] != "decentralized":
             raise NotImplementedError("centralized control is out of scope")
 
-    def _init_parsers(self):
-        self.action_space = ACTION_SPACES[self.config.signal["action_space"]](self.config, self.traffic_signals)
-        self.observation_space = OBSERVATION_SPACES[self.config.signal["observation_space"]](
-            self.config, self.parsed_network, self.traffic_signals, self.simulator_backend)
-        self.metrics = SIMULATOR_MODULES[self.simulator_backend]["metrics_parser"](
-            self.parsed_network, self.simulator, self.traffic_signals)
-        self.reward_function = REWARD_FUNCTIONS[self.config.signal["reward_function"]](
-            self.metrics, self.traffic_signals)
+    def _boot(self):
+        """Start the engine, then rebuild everything that hangs off its first measurement."""
+        self.simulator.start_simulator()
+        self._init_traffic_signals()
+        self._init_parsers()
 
     def _init_traffic_signals(self):
-        self.traffic_signals = {}
-        for ts_id, signal_config in self.parsed_network.traffic_signals.items():
-            ts = SIMULATOR_MODULES[self.simulator_backend]["traffic_signal"](ts_id, signal_config, self.simulator)
-            ts.update_stats(self.simulator.step_measurements)
-            self.traffic_signals[ts_id] = ts
+        make = self._mod["traffic_signal"]
+        self.traffic_signals = {
+            ts_id: make(ts_id, cfg, self.simulator) for ts_id, cfg in self.parsed_network.traffic_signals.items()
+        }
+        self._update_ts_stats()
 
-    def _set_n_agents(self):
-        self.n_agents = len(self.traffic_signals)
+    def _init_parsers(self):
+        sig, signals = self.config.signal, self.traffic_signals
+        self.action_space = ACTION_SPACES[sig["action_space"]](self.config, signals)
+        self.observation_space = OBSERVATION_SPACES[sig["observation_space"]](
+            self.config, self.parsed_network, signals, self.simulator_backend)
+        self.metrics = self._mod["metrics_parser"](self.parsed_network, self.simulator, signals)
+        self.reward_function = REWARD_FUNCTIONS[sig["reward_function"]](self.metrics, signals)
 
     def _update_ts_stats(self):
+        meas = self.simulator.step_measurements
         for ts in self.traffic_signals.values():
-            ts.update_stats(self.simulator.step_measurements)
+            ts.update_stats(meas)
 
+    # ---- episode bookkeeping -----------------------------------------------------------
+    @property
+    def episode_limit(self):
+        sim = self.config.simulator
+        return int(sim["episode_limit"] / sim["delta_time"])
+
+    @property
+    def episode_over(self):
+        t = self.simulator.sim_step
+        return t > 0 and t % self.config.simulator["episode_limit"] == 0
+
+    # ---- getters -----------------------------------------------------------------------
     def get_action_mask(self):
         return self.action_space.get_mask()
 
@@ -104,33 +109,33 @@ class TrafficSignalNetwork:
         return self.reward_function.get_local_reward()
 
     def get_env_info(self):
-        stats = self.metrics.get_step_stats()
-        stats.update({"episode_count": self.episode_count})
-        stats.update({"episode_limit": self.episode_limit})
-        return stats
+        info = self.metrics.get_step_stats()
+        info["episode_count"] = self.episode_count
+        info["episode_limit"] = self.episode_limit
+        return info
 
     def get_env_stats(self):
-        stats = self.get_env_info()
-        for v in self.simulator.step_measurements.values():
-            stats.update(v)
-        return stats
+        info = self.get_env_info()
+        for group in self.simulator.step_measurements.values():
+            info.update(group)
+        return info
 
-    def restart(self, reset=True):
-        if self.episode_over:
-            self.episode_count += 1
-        if self.simulator.is_terminated:
-            self.hour_count += 1
-            self.simulator.close_simulator()
-            if reset:
-                self.simulator.start_simulator()
-                self._init_traffic_signals()
-                self._init_parsers()
-
+    # ---- the hot path ------------------------------------------------------------------
     def step(self, actions):
+        """One env step = delta_time engine steps + measurement (pytsc/__init__.py:165-179)."""
         self.action_space.apply(actions)
         self.simulator.simulator_step(n_steps=self.config.simulator["delta_time"])
         self._update_ts_stats()
         return self.get_reward(), self.episode_over, self.get_env_info()
+
+    def restart(self, reset=True):
+        self.episode_count += bool(self.episode_over)
+        if not self.simulator.is_terminated:
+            return
+        self.hour_count += 1
+        self.simulator.close_simulator()
+        if reset:
+            self._boot()
 
     def close(self):
         self.simulator.shutdown()
