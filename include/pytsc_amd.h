@@ -96,7 +96,11 @@ extern "C" {
  *             tables do not fit it.
  *   AUTO      RESIDENT where it fits, else LIST.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
  *             logs resets / actions on the device: when a replica comes within 256 vehicle records of its capacity the
- *             handle moves to LIST by replaying the log (same results) -- it never overflows.  A handle forced to
+ *             handle moves to LIST by replaying the log (same results) -- it never overflows (the log holds 1024 env
+ *             steps and 64 partial restarts since the last full restart; beyond that an overflow raises the error
+ *             counter).  A full restart (tsc_reset / tsc_reset_sets with no mask or with a mask that selects every
+ *             replica) starts the log afresh and takes a migrated handle back to RESIDENT; to tell, such a handle
+ *             copies the mask to the host and synchronises the stream (restarts are rare).  A handle forced to
  *             RESIDENT has no stand-by: a spawn that finds no free record raises the error counter (tsc_errors). */
 #define TSC_FAMILY_AUTO 0
 #define TSC_FAMILY_LIST 1

@@ -314,3 +314,64 @@ def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_
     assert max(len(orc.snapshot(r)[0]) for r in range(R)) > 1100  # the run did need the room
     assert eng.errors() == 0 and orc.errors() == 0
     eng.close()
+
+
+def test_migrated_handle_returns_to_the_resident_family_at_a_full_restart(oracle_lib):
+    """kernel_family AUTO, `sequential` flow sets: run resident -> (capacity) -> list family -> full restart -> resident
+    again -> (capacity) -> list family a second time.  The second replay starts at that full restart, not at
+    tsc_create: all it needs of the past are the restart counters (the flow set of a replica is derived from them),
+    kept from before the restart.  A restart mask that selects nobody is a no-op, one that selects everybody is a full
+    restart.  Every step equals the oracle, snapshots included (they grow the handle's scratch: once a bug here)."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(flow_rate=1500.0, n_flow_sets=3, sim_length=900, episode_limit=40, flow_rate_type="sequential")
+    R = 4
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=640, **kw), family="auto")
+    orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
+    fam = lambda: eng.lib.tsc_kernel_family(eng.h)  # 1: list, 2: resident
+    assert fam() == 2
+    rng = np.random.default_rng(5)
+
+    def run(n_steps, partial_at=None):
+        out, buf = orc.observe(), eng.observe()
+        assert np.array_equal(buf["obs"].cpu().numpy(), out.obs)
+        trace = []
+        for s in range(n_steps):
+            m = out.mask
+            acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+            out = orc.step(acts)
+            buf = eng.step(torch.tensor(acts, device="cuda"))
+            assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+            assert np.array_equal(buf["stats"].cpu().numpy(), out.stats), s
+            trace.append(fam())
+            if s == partial_at:
+                mask = np.zeros(R, np.uint8)
+                mask[2] = 1
+                orc.reset(mask)
+                eng.reset(torch.tensor(mask, device="cuda"))
+                out, buf = orc.observe(), eng.observe()
+                assert np.array_equal(buf["obs"].cpu().numpy(), out.obs)
+        return trace
+
+    t1 = run(150, partial_at=20)
+    assert t1[0] == 2 and t1[-1] == 1, t1  # migrated on the way
+    for r in range(R):
+        assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
+    eng.reset(torch.zeros(R, dtype=torch.uint8, device="cuda"))  # nobody: no-op
+    assert fam() == 1
+    orc.reset(np.ones(R, np.uint8))
+    eng.reset(torch.ones(R, dtype=torch.uint8, device="cuda"))  # everybody: a full restart
+    assert fam() == 2
+    t2 = run(150, partial_at=30)
+    assert t2[0] == 2 and t2[-1] == 1, t2  # and a second migration, replayed from the full restart
+    orc.reset(None)
+    eng.reset(None)
+    assert fam() == 2
+    t3 = run(10)
+    assert set(t3) == {2}
+    for r in range(R):
+        assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
+    assert eng.errors() == 0 and orc.errors() == 0
+    eng.close()
