@@ -54,9 +54,9 @@ def main():
     buf = eng.observe()
     for _ in range(args.preroll):
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
-    out = (C.c_ulonglong * 32)()
+    out = (C.c_ulonglong * 64)()
     eng.lib.tsc_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int32]
-    eng.lib.tsc_debug_phase_cycles(eng.h, out, 32)  # drop the pre-roll
+    eng.lib.tsc_debug_phase_cycles(eng.h, out, 64)  # drop the pre-roll
     if args.ablate:
         eng.lib.tsc_debug_set_ablate(eng.h, args.ablate)
     torch.cuda.synchronize()
@@ -67,8 +67,8 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.steps
-    n = eng.lib.tsc_debug_phase_cycles(eng.h, out, 32)
-    assert n == 32, n
+    n = eng.lib.tsc_debug_phase_cycles(eng.h, out, 64)
+    assert n == 64, n
     tot = sum(out[i] for i in range(len(PHASES)))
     print(f"R={R} V/replica={eng.mean_vehicles():.0f} {ms:.3f} ms/env step (diag build, ablate {args.ablate:#x}), errors {eng.errors()}")
     for i, name in enumerate(PHASES):
@@ -82,6 +82,12 @@ def main():
     print("stats sums (one wave): %.0f; wave 5 waits at the agent barrier: %.0f" % (out[28] / n, (out[30] - out[29]) / n))
     print("exec stages per env step: A + followers %.0f, B (tasks) %.0f, C (finish) %.0f" % tuple(out[i] / n for i in (20, 21, 22)))
     print("stage A, first heavy chunk, per env step: half A1 (leader/gap + car-following) %.0f, half A2 (signal + tasks) %.0f" % (out[23] / n, out[24] / n))
+    for name, slot, parts in (("stage A1", 32, ("gathers", "leader + gap", "car-following")), ("stage A2", 36, ("signal gating", "tasks")),
+                              ("stage B task", 40, ("gathers", "cross evaluation")), ("stage C", 44, ("join", "finish + commit")),
+                              ("  cross evaluation", 52, ("cross record", "foe", "canPass"))):
+        cnt = max(int(out[slot]), 1)
+        print(f"{name}: {cnt / n / 5:.1f} wavefront runs per sub-step; cycles per run: " +
+              ", ".join(f"{q} {out[slot + 1 + i] / cnt:.0f}" for i, q in enumerate(parts)))
     print(f"items per sub-step: heavy {out[13] / n / 5:.1f}, followers {out[14] / n / 5:.1f}, cross candidates {out[15] / n / 5:.1f}")
 
 
