@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TSC_ABI_VERSION 2
+#define TSC_ABI_VERSION 3
 
 /* error codes */
 #define TSC_OK 0
@@ -95,10 +95,15 @@ extern "C" {
  *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the
  *             tables do not fit it.
  *   AUTO      RESIDENT where it fits, else LIST.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
- *             logs resets / actions on the device: when a replica comes within 256 vehicle records of its capacity the
- *             handle moves to LIST by replaying the log (same results) -- it never overflows (the log holds 1024 env
- *             steps and 64 partial restarts since the last full restart; beyond that an overflow raises the error
- *             counter).  A full restart (tsc_reset / tsc_reset_sets with no mask or with a mask that selects every
+ *             logs resets / actions on the device: when a replica comes within resident_margin (256) vehicle records of
+ *             its capacity the handle moves to LIST by replaying the log (same results).  The flag travels to the host
+ *             behind every step and is read, without synchronising, by the next tsc_step; a caller that enqueues steps
+ *             without waiting is held back so that it never runs more than 16 steps ahead of the flag.  Should a replica
+ *             run out of records all the same (more than the margin gained within those steps), it STALLS: its state
+ *             stays that of its last completed step and its outputs stay those of that step until the migration, whose
+ *             replay repairs everything -- the state after the migration is exact and tsc_errors stays 0 (the log holds
+ *             1024 env steps and 64 partial restarts since the last full restart; beyond that there is no way back and
+ *             an overflow raises the error counter).  A full restart (tsc_reset / tsc_reset_sets with no mask or with a mask that selects every
  *             replica) starts the log afresh and takes a migrated handle back to RESIDENT; to tell, such a handle
  *             copies the mask to the host and synchronises the stream (restarts are rare).  A handle forced to
  *             RESIDENT has no stand-by: a spawn that finds no free record raises the error counter (tsc_errors). */
@@ -231,7 +236,15 @@ typedef struct tsc_config {
   int32_t kernel_family;         /* TSC_FAMILY_*: which kernel family steps the replicas */
   int32_t resident_capacity;     /* resident family: vehicle records per replica (0 = default) */
   int32_t resident_threads;      /* resident family: threads per workgroup: 768 (0 = default) */
-  int32_t reserved0;             /* keep the struct a multiple of 8 bytes */
+  /* Runtime knobs of the resident family's data-dependent paths.  Results are the same, bit for bit, whatever they are
+   * set to (tests/test_hip_paths.py runs every setting against the oracle); tsc_path_counts tells which path ran. */
+  int32_t resident_force;        /* bit 0: every sub-step takes the two-phase hand-off path (else only when two hand-offs
+                                  * touch the same list end); bit 1: the measure phase walks the vehicle lists (else only
+                                  * after a vehicle left its list from behind another one) */
+  int32_t resident_task_capacity;/* (vehicle, cross) tasks per sub-step held on chip, 1..768 (0 = 768); a vehicle whose
+                                  * tasks do not fit scans its crosses serially */
+  int32_t resident_margin;       /* AUTO handles: records of headroom below which a replica asks for the migration to
+                                  * the list family (0 = 256) */
 } tsc_config_t;
 
 /* Optional outputs of tsc_step; any pointer may be NULL (skipped). */
@@ -318,6 +331,17 @@ int tsc_snapshot(tsc_handle_t h, int32_t replica, int32_t cap, int32_t *drv,
 
 /* Synchronous: device-side error counters (slot overflow etc.), 0 = clean. */
 int tsc_errors(tsc_handle_t h, int32_t *n_errors);
+
+/* Synchronous: how often the resident family took each of its data-dependent paths since tsc_create,
+ * counts[TSC_N_PATHS] int64 (all 0 for a handle on the list family):
+ *  [0] (replica, sub-step)s whose hand-offs took the two-phase path (unlink per source list, ordered append per target)
+ *  [1] (replica, env step)s whose measure phase walked the vehicle lists
+ *  [2] (vehicle, sub-step)s that scanned their crosses serially because the on-chip task list was full
+ *  [3] of [0]: not forced -- two hand-offs really touched the same list end in one sub-step
+ *  [4] of [1]: not forced -- a vehicle really left its list from behind another one
+ *  [5] replicas that ran out of records and stalled until the handle migrated */
+#define TSC_N_PATHS 8
+int tsc_path_counts(tsc_handle_t h, int64_t *counts);
 
 /* Mean number of running vehicles per replica at the last measure pass
  * (synchronous; used for reporting V_a). */

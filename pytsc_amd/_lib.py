@@ -17,7 +17,7 @@ SYMBOLS = (
     "tsc_abi_version", "tsc_create", "tsc_destroy", "tsc_reset", "tsc_step", "tsc_observe",
     "tsc_lane_detail", "tsc_snapshot", "tsc_errors", "tsc_mean_vehicles", "tsc_obs_size",
     "tsc_state_size", "tsc_n_actions", "tsc_profile_enable", "tsc_profile_read",
-    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_check_tables",
+    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_check_tables", "tsc_path_counts",
 )
 
 ERRORS = {-1: "TSC_EINVAL (bad argument / inconsistent tables)",
@@ -60,6 +60,7 @@ def load():
     lib.tsc_random_valid_actions.argtypes = [vp, vp, C.c_uint64, vp, vp]
     lib.tsc_snapshot.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.tsc_errors.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.tsc_path_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.tsc_mean_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
     lib.tsc_profile_enable.argtypes = [vp, C.c_int]
     lib.tsc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -67,7 +68,7 @@ def load():
         getattr(lib, f).argtypes = [vp]
     lib.tsc_check_tables.argtypes = [C.POINTER(TscNet), C.POINTER(TscFlows), C.POINTER(TscConfig),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    if lib.tsc_abi_version() != 2:
+    if lib.tsc_abi_version() != 3:
         raise RuntimeError("libpytsc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -160,5 +160,9 @@ struct DevCfg {
   int delta_time, yellow_time, action_space, round_robin, visibility, sim_length, episode_limit;
   int initial_wait_time, set_offset, sequential_sets, reward_kind, n_actions, obs_size, state_size;
   int ablate; // diagnostic builds only (TSC_ABLATE env): skip parts of k_enum / k_exec to price them; 0 in every real run
+  // resident family, runtime knobs of its data-dependent paths (tsc_config_t::resident_force / _task_capacity / _margin):
+  int r_force;    // bit 0: every sub-step takes the two-phase hand-off path; bit 1: the measure phase walks the lists
+  int r_task_cap; // cross tasks per sub-step held in LDS (<= R_TASKS); beyond: the vehicle scans its crosses serially
+  int r_margin;   // records of headroom below which a replica asks for the migration to the list family
   double interval, veh_size_min_gap, flickering_coef;
 };

@@ -60,7 +60,8 @@ class TscConfig(C.Structure):
         ("interval", C.c_double), ("veh_size_min_gap", C.c_double),
         ("flickering_coef", C.c_double),
         ("kernel_family", C.c_int32), ("resident_capacity", C.c_int32),
-        ("resident_threads", C.c_int32), ("reserved0", C.c_int32),
+        ("resident_threads", C.c_int32), ("resident_force", C.c_int32),
+        ("resident_task_capacity", C.c_int32), ("resident_margin", C.c_int32),
     ]
 
 
@@ -242,7 +243,9 @@ class Tables:
             1 if sim.get("flow_rate_type", "constant") == "sequential" else 0, rk,
             interval, v_size, float(config.misc["flickering_coef"]),
             {"auto": 0, "list": 1, "resident": 2}[str(sim.get("kernel_family", "auto"))],
-            int(sim.get("resident_capacity", 0)), int(sim.get("resident_threads", 0)), 0,
+            int(sim.get("resident_capacity", 0)), int(sim.get("resident_threads", 0)),
+            int(sim.get("resident_force", 0)), int(sim.get("resident_task_capacity", 0)),
+            int(sim.get("resident_margin", 0)),
         )
         self.n_replicas = int(n_replicas)
         self.obs_size = MAX_CTRL_LANES * (int(sig["visibility"]) + LANE_STATIC) + MAX_PHASES

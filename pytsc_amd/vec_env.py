@@ -182,6 +182,15 @@ class VecEngine:
         _lib.check(self.lib.tsc_errors(self.h, C.byref(e)), "tsc_errors")
         return e.value
 
+    PATH_KEYS = ("two_phase", "walk", "serial_scan", "conflict", "dirty", "stalled")
+
+    def path_counts(self):
+        """dict: how often the resident family took each of its data-dependent paths since create
+        (include/pytsc_amd.h, tsc_path_counts); synchronous."""
+        c = (C.c_int64 * 8)()
+        _lib.check(self.lib.tsc_path_counts(self.h, c), "tsc_path_counts")
+        return {k: int(c[i]) for i, k in enumerate(self.PATH_KEYS)}
+
     def mean_vehicles(self):
         m = C.c_double(0)
         _lib.check(self.lib.tsc_mean_vehicles(self.h, C.byref(m)), "tsc_mean_vehicles")
