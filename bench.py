@@ -51,6 +51,47 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets):
 
 
 # ------------------------------------------------------------------ CPU baseline
+def effective_cpus():
+    """How many host cores this process may really use: the smaller of its scheduling affinity and its cgroup's CPU
+    quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`, the process's own cgroup first, then the
+    root of the hierarchy as mounted in the container).  Returns (cores, affinity, quota or None)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+
+    def v2(path):
+        try:
+            q, per = open(path).read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+        except (OSError, ValueError):
+            return None
+
+    def v1(d):
+        try:
+            q = float(open(os.path.join(d, "cpu.cfs_quota_us")).read())
+            per = float(open(os.path.join(d, "cpu.cfs_period_us")).read())
+            return None if q <= 0 else q / per
+        except (OSError, ValueError):
+            return None
+
+    cands = []
+    try:
+        for line in open("/proc/self/cgroup"):
+            _, ctrl, path = line.strip().split(":", 2)
+            if ctrl == "":
+                cands.append(v2("/sys/fs/cgroup" + path.rstrip("/") + "/cpu.max"))
+            elif "cpu" in ctrl.split(","):
+                cands.append(v1("/sys/fs/cgroup/cpu" + path.rstrip("/")))
+                cands.append(v1("/sys/fs/cgroup/cpu,cpuacct" + path.rstrip("/")))
+    except OSError:
+        pass
+    cands += [v2("/sys/fs/cgroup/cpu.max"), v1("/sys/fs/cgroup/cpu"), v1("/sys/fs/cgroup/cpu,cpuacct")]
+    cands = [c for c in cands if c]
+    if cands:
+        quota = min(cands)
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return cores, aff, quota
+
+
 def _cpu_worker(tables, seed, warmup, budget_s, start_at, q):
     """One process: the scalar f64 oracle on one replica of the workload, random valid
     actions, `warmup` untimed env steps, then as many env steps as fit in budget_s."""
@@ -95,7 +136,7 @@ def cpu_baseline(rows, cols, rate, warmup, budget_s):
     tables = workload_tables(rows, cols, 1, 0, rate, 1)  # built once, shared with the workers by fork
     A = tables.n_agents
     ctx = mp.get_context("fork")
-    n_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_cores, affinity, quota = effective_cpus()
 
     def run(n_procs, budget):
         q = ctx.Queue()
@@ -113,23 +154,49 @@ def cpu_baseline(rows, cols, rate, warmup, budget_s):
     return {
         "value": vall, "unit": "agent-env-steps/s", "cores": n_cores, "kind": "port",
         "value_1core": v1,
+        # oversubscription shows here: each of the n_cores processes should run near the 1-core rate
+        "value_per_process": vall / n_cores, "per_process_vs_1core": (vall / n_cores) / v1 if v1 else None,
+        "affinity_cores": affinity, "cgroup_quota_cores": quota,
         "sample": f"CPU restatement (oracle), not CityFlow: 1 replica of the same {rows}x{cols} workload per "
                   f"process, random valid actions, {warmup} untimed env steps (network filling) then {dtall:.1f} s "
-                  f"timed; {n_cores} processes (one per host core): {nall} env steps; 1 process on 1 core: "
+                  f"timed; {n_cores} processes (cores = min(scheduling affinity {affinity}, cgroup CPU quota "
+                  f"{'none' if quota is None else f'{quota:.1f}'})): {nall} env steps; 1 process on 1 core: "
                   f"{n1} env steps in {dt1:.1f} s",
     }
 
 
 # ------------------------------------------------------------------ launcher
+def count_gpus_without_hip():
+    """GPUs of this node as the kernel driver lists them (KFD topology: a node with SIMDs is a GPU), without loading
+    or initialising the HIP runtime in this process -- the launcher parent must stay clean of it, its children
+    initialise the GPU themselves.  None when the topology is not readable (then the workers find out)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(root, node, "properties")) if line.strip())
+        except (OSError, ValueError):
+            continue
+        if int(props.get("simd_count", 0)) > 0:
+            n += 1
+    visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if visible is not None and visible.strip() != "":
+        n = min(n, len([v for v in visible.split(",") if v.strip() != ""]))
+    return n
+
+
 def launch_workers(args, argv):
-    """--gpus N > 1 without a distributed launcher: start N fresh worker processes.  Nothing in
-    this process has touched the GPU (torch.cuda.device_count() does not initialise it)."""
+    """--gpus N > 1 without a distributed launcher: start N fresh worker processes.  This process never touches the
+    HIP runtime (GPUs are counted from the KFD topology in sysfs).  The children are polled together: the first one that
+    fails takes the others down at once (they would otherwise sit in the rendezvous until its timeout)."""
     n = args.gpus
     if not args.stub:
-        import torch
-
-        have = torch.cuda.device_count()
-        if have < n:
+        have = count_gpus_without_hip()
+        if have is not None and have < n:
             sys.stderr.write(f"bench.py: --gpus {n} requested but this node has {have} GPU(s)\n")
             return 2
     import socket
@@ -142,7 +209,24 @@ def launch_workers(args, argv):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rcs = [p.wait() for p in procs]
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):  # a rank failed: stop the rest now (fresh children only; never an exec)
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
     if any(rcs):
         sys.stderr.write(f"bench.py: worker exit codes {rcs}\n")
         return 1

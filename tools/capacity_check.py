@@ -26,4 +26,5 @@ for s in range(719):
         eng.lib.tsc_replica_counts(eng.h, C.c_void_p(counts.data_ptr()), None)
         torch.cuda.synchronize()
         live = counts[:, 1]
-        print(f"step {s + 1}: live vehicles per replica mean {live.float().mean():.0f} max {int(live.max())}, errors {eng.errors()}, family {eng.lib.tsc_kernel_family(eng.h)}", flush=True)
+        q = torch.quantile(live.float(), torch.tensor([0.5, 0.9, 0.99], device=live.device)).tolist()
+        print(f"step {s + 1}: live vehicles per replica mean {live.float().mean():.0f} p50 {q[0]:.0f} p90 {q[1]:.0f} p99 {q[2]:.0f} max {int(live.max())}, errors {eng.errors()}, family {eng.lib.tsc_kernel_family(eng.h)}", flush=True)
