@@ -196,7 +196,7 @@ def test_async_caller_across_the_migration_threshold(oracle_lib):
         out = orc.step(acts)
         acts_all.append(acts)
         exp.append((out.obs.copy(), out.stats.copy(), out.mask.copy()))
-    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=640, **kw), family="auto")
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, **kw), family="auto")
     assert eng.family == "resident"
     acts_dev = torch.tensor(np.stack(acts_all), device="cuda")
     torch.cuda.synchronize()
@@ -227,7 +227,7 @@ def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(or
     from pytsc_amd.vec_env import VecEngine
 
     kw = dict(flow_rate=1800.0, n_flow_sets=2, sim_length=1500, episode_limit=500)
-    R, steps = 6, 270  # (the layout's smallest capacity is 1472 records: the grid has to hold that many)
+    R, steps = 6, 270  # (the grid has to hold more than 1472 vehicles + the stage scratch of its heavy ones)
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
     rng = np.random.default_rng(22)
     out = orc.observe()
@@ -238,7 +238,7 @@ def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(or
         out = orc.step(acts)
         acts_all.append(acts)
         exp.append(out.obs.copy())
-    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=640, resident_margin=1, **kw), family="auto")
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_margin=1, **kw), family="auto")
     acts_dev = torch.tensor(np.stack(acts_all), device="cuda")
     torch.cuda.synchronize()
     got, fam = [], []

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--cols", type=int, default=4)
     ap.add_argument("--threads", type=int, default=0, help="resident family: threads per workgroup")
     ap.add_argument("--ablate", type=lambda x: int(x, 0), default=0, help="ablation bits set after the pre-roll")
+    ap.add_argument("--lib", default=DIAG, help="the -DTSC_DIAG build to profile")
     args = ap.parse_args()
     if args.build:
         build()
@@ -41,7 +42,7 @@ def main():
 
     from pytsc_amd import _lib
 
-    _lib.LIB_PATH = DIAG
+    _lib.LIB_PATH = os.path.abspath(args.lib)
     import bench
     from pytsc_amd.vec_env import VecEngine
 
