@@ -1,45 +1,37 @@
-"""Small helpers with the reference's behaviour (pytsc/common/utils.py)."""
+"""Small helpers behaving as the reference's (pytsc/common/utils.py:9-112): the logger facade, the allowed-value
+check of the config strings and the integer-truncating padding."""
 import logging
 
 import numpy as np
 
+log = logging.getLogger("pytsc_amd")
+if not log.handlers:
+    _h = logging.StreamHandler()
+    _h.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
+    log.addHandler(_h)
+    log.setLevel(logging.INFO)
+
 
 class EnvLogger:
-    logger = None
+    """Name kept for callers of the reference's helper (EnvLogger.set_log_level(logging.WARNING) is how its users
+    silence the config dump); everything goes to the package logger `pytsc_amd`."""
 
-    @staticmethod
-    def get_logger(name=__name__, level=logging.INFO):
-        if EnvLogger.logger is None:
-            EnvLogger.logger = logging.getLogger(name)
-            if not EnvLogger.logger.hasHandlers():
-                h = logging.StreamHandler()
-                h.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
-                EnvLogger.logger.addHandler(h)
-            EnvLogger.logger.setLevel(level)
-        return EnvLogger.logger
-
-    @staticmethod
-    def log_info(msg):
-        EnvLogger.get_logger().log(logging.INFO, msg)
-
-    @staticmethod
-    def log_warning(msg):
-        EnvLogger.get_logger().log(logging.WARNING, msg)
-
-    @staticmethod
-    def set_log_level(level):
-        EnvLogger.get_logger().setLevel(level)
+    get_logger = staticmethod(lambda name=None, level=None: log)
+    log_info = staticmethod(log.info)
+    log_warning = staticmethod(log.warning)
+    set_log_level = staticmethod(log.setLevel)
 
 
-def validate_input_against_allowed(inp_cfg_str, allowed_cfg_strs):
-    assert (
-        inp_cfg_str in allowed_cfg_strs
-    ), f"Invalid action space `{inp_cfg_str}`. Allowed values are {allowed_cfg_strs}."
+def validate_input_against_allowed(value, allowed):
+    """The reference rejects an unknown config string with an AssertionError (utils.py:52-55); so does this."""
+    allowed = list(allowed)
+    if value not in allowed:
+        raise AssertionError(f"`{value}` is not one of the supported values {allowed}")
 
 
 def pad_list(inp_list, size, pad_value=0):
     """Reference semantics (utils.py:91-112): pads through an array created with
-    np.full(size, pad_value) — an INTEGER pad value therefore truncates every
+    np.full(size, pad_value) -- an INTEGER pad value therefore truncates every
     float entry toward zero whenever padding happens."""
     arr = np.asarray(np.array(inp_list))
     if len(arr) >= size:

@@ -218,6 +218,21 @@ class VecTrafficSignalNetwork:
         from pytsc_amd.scenario import build_tables
 
         self.config = Config(scenario, **kwargs)
+        sig = self.config.signal
+        self.obs_kind = sig.get("observation_space", "position_matrix")
+        if self.obs_kind not in ("position_matrix", "lane_features"):
+            raise ValueError(f"observation_space {self.obs_kind!r}: expected position_matrix or lane_features")
+        if float(sig.get("obs_noise_std", 0.0) or 0.0) != 0.0:
+            # reference common/observations.py:72-88 draws one np.random.normal per surviving bin of the FLOAT position
+            # matrix; the batched path keeps the matrices as predicate bits on the device.  Not silently ignored:
+            raise ValueError("obs_noise_std > 0 is served by the single-env facade (pytsc_amd.TrafficSignalNetwork, "
+                             "numpy-stream parity with the reference), not by the batched VecTrafficSignalNetwork")
+        self.dropout_prob = float(sig.get("obs_dropout_prob", 0.0) or 0.0)
+        if self.dropout_prob and self.obs_kind != "lane_features":
+            raise ValueError("obs_dropout_prob applies to observation_space: lane_features (reference "
+                             "common/observations.py:245-253)")
+        if self.obs_kind == "lane_features" and "state" not in outputs:
+            outputs = tuple(outputs) + ("state",)  # the lane-feature observation is assembled with the state rows
         self.tables = build_tables(self.config, n_replicas=n_replicas, set_offset=set_offset)
         self.parsed_network = self.tables.parser
         self.engine = VecEngine(self.tables, device=device, want=tuple(outputs))
@@ -227,13 +242,56 @@ class VecTrafficSignalNetwork:
         self.buf = self.engine.observe()
         self.episode_count = 0
         self._set_rng = torch.Generator().manual_seed(int(self.config.simulator["seed"]))
+        self._drop_rng = torch.Generator(device=self.engine.device).manual_seed(int(self.config.simulator["seed"]) + 1)
+        self._keep = None  # [R, A, state_size] 0/1 multiplier of the lane-feature observation (lane dropout)
+        self._dropped = None
+        if self.obs_kind == "lane_features":
+            self._lane_slot = self._lane_slots()
+            self.reset_dropped_lanes()
 
     @property
     def episode_limit(self):
         return int(self.config.simulator["episode_limit"] / self.config.simulator["delta_time"])
 
     def get_observation_size(self):
-        return self.engine.obs_size
+        return self.engine.state_size if self.obs_kind == "lane_features" else self.engine.obs_size
+
+    # -- observation_space: lane_features (reference common/observations.py:225-382) on the device ------------------
+    def _lane_slots(self):
+        """[A, 16] int64: network lane index of the k-th incoming lane of agent a (-1: padding)."""
+        rn = self.tables.rn
+        slots = torch.full((self.n_agents_static(), 16), -1, dtype=torch.int64)
+        for a, ts_id in enumerate(rn.agent_ids):
+            for k, lane in enumerate(self.parsed_network.traffic_signals[ts_id]["incoming_lanes"]):
+                slots[a, k] = rn.lane_index[lane]
+        return slots.to(self.engine.device)
+
+    def n_agents_static(self):
+        return self.tables.n_agents
+
+    def reset_dropped_lanes(self, replicas=None):
+        """Draw the dropped lanes anew (reference LaneFeatures.reset_dropped_lanes: int(p * n_lanes) lanes without
+        replacement) -- per replica, from a counter-based device generator (the reference's numpy stream cannot be
+        followed by R replicas at once; the single-env facade does follow it).  `replicas`: [R] bool, None = all."""
+        if self.obs_kind != "lane_features":
+            return
+        R, nl = self.n_replicas_static(), self.tables.n_lanes
+        n_drop = int(self.dropout_prob * nl)
+        dropped = torch.zeros((R, nl + 1), dtype=torch.bool, device=self.engine.device)  # (+1: the padding slot)
+        if n_drop:
+            order = torch.rand((R, nl), device=self.engine.device, generator=self._drop_rng).argsort(dim=1)
+            dropped[:, :nl].scatter_(1, order[:, :n_drop], True)
+        if replicas is not None and self._dropped is not None:
+            dropped = torch.where(replicas.to(torch.bool)[:, None], dropped, self._dropped)
+        self._dropped = dropped
+        lane_dropped = dropped[:, self._lane_slot]  # [R, A, 16] (slot -1 reads the padding column: never dropped)
+        keep = torch.ones((R, self.tables.n_agents, self.engine.state_size), dtype=torch.float32, device=self.engine.device)
+        body = keep[:, :, :16 * 12].view(R, self.tables.n_agents, 16, 12)
+        body[:, :, :, 9:12] = (~lane_dropped).to(torch.float32)[..., None]
+        self._keep = keep if n_drop else None
+
+    def n_replicas_static(self):
+        return self.tables.n_replicas
 
     def get_state_size(self):
         return self.engine.state_size
@@ -242,6 +300,10 @@ class VecTrafficSignalNetwork:
         return self.engine.n_actions
 
     def get_observations(self):
+        if self.obs_kind == "lane_features":
+            # == the state rows with the three measured entries of dropped lanes zeroed (observations.py:305-329)
+            st = self.buf["state"]
+            return st if self._keep is None else st * self._keep
         return self.buf["obs"]
 
     def get_state(self):

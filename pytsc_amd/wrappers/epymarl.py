@@ -9,8 +9,35 @@ except Exception:  # pragma: no cover
         pass
 
 
+def _delegate(path, call=True):
+    """A method that forwards to `self.tsc_env.<path>` (called, or read as an attribute)."""
+    parts = path.split(".")
+
+    def method(self):
+        obj = self.tsc_env
+        for p in parts:
+            obj = getattr(obj, p)
+        return obj() if call else obj
+
+    method.__doc__ = f"tsc_env.{path}{'()' if call else ''}"
+    return method
+
+
 class EPyMARLTrafficSignalNetwork(MultiAgentEnv):
+    """The SMAC / EPyMARL method set over one TrafficSignalNetwork.  Most of it is a one-to-one renaming of the env's own
+    getters (the table below); what has behaviour of its own -- reward scalarisation, `reset` without a simulator reset --
+    is written out."""
+
     step_stats = None
+    # wrapper method -> what it returns of the env (reference wrappers/epymarl.py:35-103)
+    _FORWARDED = {
+        "close": ("close", True), "get_avail_actions": ("get_action_mask", True), "get_obs": ("get_observations", True),
+        "get_obs_size": ("get_observation_size", True), "get_state": ("get_state", True),
+        "get_state_size": ("get_state_size", True), "get_local_rewards": ("get_rewards", True),
+        "get_stats": ("get_env_stats", True), "get_total_actions": ("get_action_size", True),
+        "get_network_flow": ("metrics.network_flow", False), "get_pressures": ("metrics.pressures", False),
+        "is_terminated": ("simulator.is_terminated", False), "sim_step": ("simulator.sim_step", False),
+    }
 
     def __init__(self, map_name="syn_2x2", simulator_backend="hip", **kwargs):
         kwargs.pop("scenario", None)
@@ -22,73 +49,38 @@ class EPyMARLTrafficSignalNetwork(MultiAgentEnv):
     def apply_actions(self, actions):
         self.tsc_env.action_space.apply(actions)
 
-    def close(self):
-        self.tsc_env.close()
-
-    def get_avail_actions(self):
-        return self.tsc_env.get_action_mask()
-
     def get_env_info(self):
-        return {
-            "agents": list(self.tsc_env.traffic_signals.keys()),
-            "episode_limit": self.episode_limit,
-            "n_actions": self.get_total_actions(),
-            "adjacency_matrix": self.tsc_env.parsed_network.adjacency_matrix,
-            "n_agents": self.tsc_env.n_agents,
-            "obs_shape": self.get_obs_size(),
-            "obs_info": self.tsc_env.observation_space.get_observation_info(),
-            "state_shape": self.get_state_size(),
-            "lane_features": self.tsc_env.observation_space.get_per_agent_lane_features(),
-        }
-
-    def get_obs(self):
-        return self.tsc_env.get_observations()
-
-    def get_obs_size(self):
-        return self.tsc_env.get_observation_size()
-
-    def get_network_flow(self):
-        return self.tsc_env.metrics.network_flow
-
-    def get_pressures(self):
-        return self.tsc_env.metrics.pressures
-
-    def get_state(self):
-        return self.tsc_env.get_state()
-
-    def get_local_rewards(self):
-        return self.tsc_env.get_rewards()
-
-    def get_state_size(self):
-        return self.tsc_env.get_state_size()
-
-    def get_stats(self):
-        return self.tsc_env.get_env_stats()
-
-    def get_total_actions(self):
-        return self.tsc_env.get_action_size()
-
-    def is_terminated(self):
-        return self.tsc_env.simulator.is_terminated
-
-    def sim_step(self):
-        return self.tsc_env.simulator.sim_step
+        env, space = self.tsc_env, self.tsc_env.observation_space
+        return dict(
+            agents=list(env.traffic_signals.keys()), episode_limit=self.episode_limit, n_actions=self.get_total_actions(),
+            adjacency_matrix=env.parsed_network.adjacency_matrix, n_agents=env.n_agents, obs_shape=self.get_obs_size(),
+            obs_info=space.get_observation_info(), state_shape=self.get_state_size(),
+            lane_features=space.get_per_agent_lane_features(),
+        )
 
     def reset(self):
-        self.tsc_env.episode_count += 1
-        obs, state = self.get_obs(), self.get_state()
-        if self.tsc_env.episode_over:
-            self.tsc_env.restart()
-        return obs, state
+        """SMAC's reset: a new episode of the SAME simulated hour -- the simulator restarts only when its hour is over."""
+        env = self.tsc_env
+        env.episode_count += 1
+        snapshot = (self.get_obs(), self.get_state())
+        if env.episode_over:
+            env.restart()
+        return snapshot
 
     def step(self, actions):
-        reward, episode_over, env_info = self.tsc_env.step(actions)
-        if self.common_reward:
-            if self.reward_scalarization == "mean":
-                reward = reward / self.tsc_env.n_agents
-        else:
+        env = self.tsc_env
+        global_reward, episode_over, info = env.step(actions)
+        if not self.common_reward:
             reward = self.get_local_rewards()
-        return self.get_obs(), reward, episode_over, False, env_info
+        elif self.reward_scalarization == "mean":
+            reward = global_reward / env.n_agents
+        else:
+            reward = global_reward
+        return self.get_obs(), reward, episode_over, False, info
+
+
+for _name, (_path, _call) in EPyMARLTrafficSignalNetwork._FORWARDED.items():
+    setattr(EPyMARLTrafficSignalNetwork, _name, _delegate(_path, _call))
 
 
 def _pad_rows(rows, n_rows, fill_row):

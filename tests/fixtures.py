@@ -32,9 +32,10 @@ def load_case(name, n_replicas=1):
     entries = expand_flows(inputs["flows"])
     cfg = Config(
         name,
-        hip={"roadnet_json": net, "flow_entries": [entries]},
+        hip=dict({"roadnet_json": net, "flow_entries": [entries]}, **inputs.get("backend", {})),
         signal=dict(inputs["signal"]),
         misc=dict(inputs["misc"]),
+        network=dict(inputs.get("network", {})),
     )
     tables = build_tables(cfg, n_replicas=n_replicas)
     return inputs, exp, parser, cfg, tables

@@ -77,6 +77,25 @@ CASES = {
         signal={"action_space": "phase_selection", "round_robin": False},
         policy="random",
     ),
+    # ---- parser overrides: `phase_sequence` (backends/cityflow/network_parser.py:52-57; the
+    #      shipped new_york_arterial scenario sets exactly this list) and `neighbors` (common/network_parser.py:19-35)
+    "syn_2x2_phase_sequence": dict(
+        roadnet=("grid", 2, 2), flows=("poisson", 600.0, 4), steps=80,
+        signal={"action_space": "phase_switch", "round_robin": True},
+        cityflow={"phase_sequence": [1, 0, 3, 0, 2, 0, 4, 0]},
+        policy="random",
+    ),
+    "syn_2x3_neighbors_override": dict(
+        roadnet=("grid", 2, 3), flows=("poisson", 600.0, 5), steps=80,
+        signal={"action_space": "phase_selection", "round_robin": False},
+        misc={"max_hops": 2},
+        # east-west chains only (the road graph would also link the two rows), and not symmetric on purpose
+        network={"neighbors": {
+            "intersection_1_1": ["intersection_2_1"], "intersection_2_1": ["intersection_1_1", "intersection_3_1"],
+            "intersection_3_1": ["intersection_2_1"], "intersection_1_2": ["intersection_2_2"],
+            "intersection_2_2": ["intersection_3_2"], "intersection_3_2": ["intersection_2_2", "intersection_3_1"]}},
+        policy="random",
+    ),
     # ---- "next" rows: the reference's rule-based controllers drive the env
     # (pytsc/controllers/controllers.py:57-242); every step also records, for every signal and phase, the
     # allowable-switch flags and the three scores the controllers rank phases by (stopped vehicles, pressure,
@@ -141,12 +160,14 @@ def _make_scenario_dir(root, name, case):
     import yaml
 
     scen_cfg = {
-        "cityflow": {"roadnet_file": "roadnet.json", "flow_file": "flows.json",
-                     "roadnet_log_file": "roadnet_log_file.json",
-                     "replay_log_file": "replay_log_file.txt", "save_replay": False},
+        "cityflow": dict({"roadnet_file": "roadnet.json", "flow_file": "flows.json",
+                          "roadnet_log_file": "roadnet_log_file.json",
+                          "replay_log_file": "replay_log_file.txt", "save_replay": False}, **case.get("cityflow", {})),
         "signal": dict(case.get("signal", {})),
         "misc": dict(case.get("misc", {})),
     }
+    if "network" in case:
+        scen_cfg["network"] = dict(case["network"])
     with open(os.path.join(sdir, "config.yaml"), "w") as f:
         yaml.safe_dump(scen_cfg, f)
     return net, entries
@@ -305,6 +326,7 @@ def generate(name):
         "roadnet": {"grid": list(case["roadnet"][1:])} if case["roadnet"][0] == "grid" else {"net": net},
         "flows": compact_flows(entries),
         "signal": case.get("signal", {}), "misc": case.get("misc", {}),
+        "network": case.get("network", {}), "backend": case.get("cityflow", {}),
         "info_keys": list(info_keys),
     }
     with gzip.open(os.path.join(out_dir, "inputs.json.gz"), "wt") as f:

@@ -211,3 +211,32 @@ def test_domain_randomized_wrapper_pads_to_the_largest_map():
         assert done
     assert seen == set(maps)  # both maps were drawn
     env.close()
+
+
+@pytest.mark.parametrize("case", ["syn_2x2_selection_rr", "syn_1x3_switch_rr"])
+def test_trad_controller_actions_entry_point(case):
+    """action_space.get_trad_controller_actions (reference common/actions.py:64-84,190-211): the facade's entry point for
+    the rule-based controllers.  phase_selection: the controllers' phase picks themselves, "random" a mask-weighted draw
+    of Python's `random`; phase_switch: 1 where the pick differs from the current phase index, else 0."""
+    import random
+
+    env, inputs = make_env(case)
+    switch = inputs["signal"]["action_space"] == "phase_switch"
+    for s in range(25):
+        for ctrl in ("greedy", "max_pressure", "sotl", "fixed_time"):
+            np.random.seed(7 * s + 1)  # (greedy / max_pressure break ties with numpy's global stream)
+            picks = [ts.get_controller_action(ctrl) for ts in env.traffic_signals.values()]
+            np.random.seed(7 * s + 1)
+            acts = env.action_space.get_trad_controller_actions(ctrl)
+            cur = [ts.controller.program.current_phase_index for ts in env.traffic_signals.values()]
+            assert acts == ([int(p != c) for p, c in zip(picks, cur)] if switch else picks), (s, ctrl)
+        random.seed(100 + s)
+        acts = env.action_space.get_trad_controller_actions("random")
+        mask = env.get_action_mask()
+        random.seed(100 + s)
+        for i, ts in enumerate(env.traffic_signals.values()):
+            pick = random.choices([0, 1] if switch else range(ts.controller.n_phases), weights=mask[i])[0]
+            want = int(ts.controller.program.current_phase_index != pick) if switch else pick
+            assert acts[i] == want, (s, i)
+        env.step(env.action_space.get_trad_controller_actions("sotl" if s % 2 else "greedy"))
+    env.close()
