@@ -36,6 +36,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X"
 DEFAULT_OUTPUTS = "obs,mask,local_reward,global_reward,done,terminated,stats"
+MAX_DISTINCT_DEMANDS = 64
 
 
 def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="grid"):
@@ -50,11 +51,21 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="
 
         return load_case("jinan_3_4_random", n_replicas=n_replicas)[4]
 
-    cfg = Config(
-        f"syn_{rows}x{cols}",
-        signal={"action_space": "phase_selection", "round_robin": False},
-        hip={"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0},
-    )
+    hip = {"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0}
+    if n_sets > MAX_DISTINCT_DEMANDS:
+        # many flow sets (the --flow-sets sweep up to one per replica): generating a demand costs the host half a second,
+        # so at most 64 distinct demands are generated and stored n_sets / 64 times each -- every set still has its own
+        # copy of the per-set device tables (spawn queues, path table), which is what the sweep measures
+        from pytsc_amd.flows import poisson_flows
+        from pytsc_amd.grid import generate_grid
+        from pytsc_amd.roadnet import RoadNet
+
+        rn = RoadNet(generate_grid(rows, cols))
+        base = Config(f"syn_{rows}x{cols}").simulator
+        horizon = int(base["sim_length"]) + int(base["initial_wait_time"])
+        distinct = [poisson_flows(rn, rate, horizon, seed=i) for i in range(MAX_DISTINCT_DEMANDS)]
+        hip = {"flow_entries": [distinct[i % MAX_DISTINCT_DEMANDS] for i in range(n_sets)]}
+    cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
     return build_tables(cfg, n_replicas=n_replicas, set_offset=set_offset)
 
 
