@@ -139,6 +139,8 @@ struct DevState {
   int *cur_idx, *top, *changed;
   AgentRec *arec; // raw phase + cross-candidate masks, read together by k_exec
   double *agent_local, *agent_pressure;
+  double *net_sums; // [3 * RS]: density, normalised mean speed, speed x n summed over all lanes in lane order (k_net_sums)
+  int *net_cnt;     // [2 * RS]: queued vehicles, vehicles on all lanes
   // per replica [RS]
   int *t, *set, *restarts, *fin_cnt;
   int *nq_all; // queued vehicles on ALL lanes (Q6), accumulated by k_measure, consumed + zeroed by k_stats

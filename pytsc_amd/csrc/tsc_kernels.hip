@@ -1830,6 +1830,88 @@ __device__ double np_pairwise_sum_col(const double *a, size_t stride, int n) {
   }
 }
 
+// The three ordered f64 sums over ALL lanes of the info dict (the reference uses Python's `sum`: sequential adds in lane
+// order, so the order is part of the result) and the two integer totals, for 64 replicas per workgroup.  One thread per
+// replica walking 3 264 lanes (16x16) is a chain of dependent memory round trips: 3.2 ms per env step, a quarter of the
+// GPU time of that configuration (profiles/r03_c16_kernel_stats.csv).  Here the TERMS of a stage of NS_LANES lanes are
+// computed by fifteen loader wavefronts (lane-of-wave <-> replica: coalesced 256 / 512-byte rows, the f64 divisions
+// of different lanes side by side) into LDS, double-buffered, while wavefront 0 adds the previous stage's terms in lane
+// order: the same operations on the same operands in the same order per replica, the round trips overlapped.
+#define NS_WAVES 16
+#define NS_LANES 30 /* lanes per stage: two per loader wavefront */
+__global__ __launch_bounds__(64 * NS_WAVES) void k_net_sums(DevNet N, DevState S, DevCfg C) {
+  __shared__ double t_occ[2][NS_LANES][64], t_nm[2][NS_LANES][64], t_mv[2][NS_LANES][64];
+  __shared__ int t_cnt[NS_WAVES][2][64];
+  const int lx = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+  const int r = (int)blockIdx.x * 64 + lx;
+  const bool rv = r < S.R;
+  const int nl = N.n_lanes, n_stage = (nl + NS_LANES - 1) / NS_LANES;
+  int nq = 0, nveh = 0;
+  double dens = 0, nms = 0, tvs = 0;
+  auto load_stage = [&](int st) {
+    if (w == 0) return;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int slot = (w - 1) * 2 + j, l = st * NS_LANES + slot;
+      double occ = 0.0, nm = 0.0, mv = 0.0;
+      if (rv && l < nl) {
+        const int n = S.lane_n[IDX(l)];
+        nq += S.lane_q[IDX(l)];
+        nveh += n;
+        occ = n / (N.lane_len_pytsc[l] / C.veh_size_min_gap);
+        const double m = n == 0 ? 0.0 : S.lane_sum[IDX(l)] / n;
+        nm = m / N.drv_max_speed[l];
+        mv = m * n;
+      }
+      t_occ[st & 1][slot][lx] = occ;
+      t_nm[st & 1][slot][lx] = nm;
+      t_mv[st & 1][slot][lx] = mv;
+    }
+  };
+  load_stage(0);
+  __syncthreads();
+  for (int st = 0; st < n_stage; st++) {
+    if (st + 1 < n_stage) load_stage(st + 1);
+    if (w == 0) {
+      const int cnt = nl - st * NS_LANES < NS_LANES ? nl - st * NS_LANES : NS_LANES;
+      for (int j = 0; j < cnt; j++) { // (a lane beyond the last adds nothing: not even + 0.0)
+        dens += t_occ[st & 1][j][lx];
+        nms += t_nm[st & 1][j][lx];
+        tvs += t_mv[st & 1][j][lx];
+      }
+    }
+    __syncthreads();
+  }
+  t_cnt[w][0][lx] = nq;
+  t_cnt[w][1][lx] = nveh;
+  __syncthreads();
+  if (w == 0 && rv) {
+    int q = 0, v = 0;
+    for (int i = 0; i < NS_WAVES; i++) {
+      q += t_cnt[i][0][lx];
+      v += t_cnt[i][1][lx];
+    }
+    S.net_sums[IDX(0)] = dens;
+    S.net_sums[IDX(1)] = nms;
+    S.net_sums[IDX(2)] = tvs;
+    S.net_cnt[IDX(0)] = q;
+    S.net_cnt[IDX(1)] = v;
+  }
+}
+
+// Neighbour-mixed local rewards (reference common/reward.py:67-88): one thread per (agent, replica) instead of a loop
+// over the agents inside k_stats; the adds of one agent's neighbours keep their order.
+__global__ void k_local_rewards(DevNet N, DevState S, tsc_step_out_t out, int n_rb, int n_ablk) {
+  int rb, ab;
+  if (!map_block(n_rb, n_ablk, rb, ab)) return;
+  const int r = rb * 64 + (int)threadIdx.x, a = ab * (int)blockDim.y + (int)threadIdx.y;
+  if (r >= S.R || a >= N.n_agents) return;
+  double rew = S.agent_local[IDX(a)];
+  for (int k = N.agent_nbr_ptr[a]; k < N.agent_nbr_ptr[a + 1]; k++) rew += N.agent_nbr_w[k] * S.agent_local[IDX(N.agent_nbr[k])];
+  if (out.local_reward_dev) out.local_reward_dev[(size_t)r * N.n_agents + a] = (float)rew;
+  if (out.local_reward64_dev) out.local_reward64_dev[(size_t)r * N.n_agents + a] = rew;
+}
+
 // Network metrics, rewards, episode flags (reference backends/cityflow/metrics.py:24-260,
 // common/reward.py:54-88,106-136, pytsc/__init__.py:58-62, simulator.py:20-30).
 __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
@@ -1839,15 +1921,12 @@ __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
   long long nq_all = S.nq_all[r], nveh_all = 0;
   S.nq_all[r] = 0;
   double dens = 0, nms = 0, tvs = 0;
-  if (out.stats_dev) nq_all = 0;
-  for (int l = 0; out.stats_dev && l < N.n_lanes; l++) {
-    int n = S.lane_n[IDX(l)];
-    nq_all += S.lane_q[IDX(l)];
-    nveh_all += n;
-    dens += lane_occupancy(N, S, C, r, l);
-    double m = n == 0 ? 0.0 : S.lane_sum[IDX(l)] / n;
-    nms += m / N.drv_max_speed[l];
-    tvs += m * n;
+  if (out.stats_dev) { // (k_net_sums, launched just before: the lane sums in lane order)
+    dens = S.net_sums[IDX(0)];
+    nms = S.net_sums[IDX(1)];
+    tvs = S.net_sums[IDX(2)];
+    nq_all = S.net_cnt[IDX(0)];
+    nveh_all = S.net_cnt[IDX(1)];
   }
   double density = dens / N.n_lanes;
   double norm_mean_speed = nms / N.n_lanes;
@@ -1869,15 +1948,6 @@ __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
   }
   if (out.global_reward_dev) out.global_reward_dev[r] = (float)g;
   if (out.global_reward64_dev) out.global_reward64_dev[r] = g;
-  if (out.local_reward_dev || out.local_reward64_dev) {
-    for (int a = 0; a < A; a++) {
-      double rew = S.agent_local[IDX(a)];
-      for (int k = N.agent_nbr_ptr[a]; k < N.agent_nbr_ptr[a + 1]; k++)
-        rew += N.agent_nbr_w[k] * S.agent_local[IDX(N.agent_nbr[k])];
-      if (out.local_reward_dev) out.local_reward_dev[(size_t)r * A + a] = (float)rew;
-      if (out.local_reward64_dev) out.local_reward64_dev[(size_t)r * A + a] = rew;
-    }
-  }
   int step = S.t[r] + 1; // engine steps completed
   int sim_step = step - C.initial_wait_time;
   if (out.stats_dev) {
