@@ -133,6 +133,7 @@ class FlowCompiler:
         self.tmpls = []
         self.tmpl_index = {}
         self.sets = []
+        self._compiled = {}  # id(entries) -> (entries, FlowSet): a demand given several times is expanded once
 
     def _route_id(self, roads):
         key = tuple(roads)
@@ -160,6 +161,10 @@ class FlowCompiler:
         while now >= interval a vehicle is created and now -= interval; then
         now += dt.  Vehicles of one step are ordered by entry index.
         """
+        hit = self._compiled.get((id(entries), sim_len))
+        if hit is not None and hit[0] is entries:
+            self.sets.append(hit[1])
+            return hit[1]
         dt = self.interval
         per_step = []
         for fi, e in enumerate(entries):
@@ -197,6 +202,7 @@ class FlowCompiler:
             [t[1] for t in per_step], [t[2] for t in per_step],
         )
         self.sets.append(fs)
+        self._compiled[(id(entries), sim_len)] = (entries, fs)
         return fs
 
 

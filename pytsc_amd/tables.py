@@ -211,21 +211,31 @@ class Tables:
         veh_route = cat([s.veh_route for s in sets])
         veh_start = cat([s.veh_start for s in sets])
         veh_tmpl = cat([s.veh_tmpl for s in sets])
-        spawn_lists = []
+        # per set (numpy; a set object that occurs several times -- many replicas' worth of tiled demands -- is
+        # processed once): the vehicles of each lane's spawn queue in creation order, the creation prefix tables
+        route_first = np.asarray([r[0] for r in flow_compiler.routes] or [0], dtype=np.int64)
+        per_set = {}
+        spawn_cnt = np.zeros((len(sets), nl), dtype=np.int64)
+        spawn_vids = []
         created_cnt = np.zeros((len(sets), sim_len + 2), dtype=np.int32)
         created_tsum = np.zeros((len(sets), sim_len + 2), dtype=np.int64)
         for si, s in enumerate(sets):
-            per_lane = [[] for _ in range(nl)]
-            for vid in range(s.n_veh):
-                first = flow_compiler.routes[s.veh_route[vid]][0]
-                per_lane[first].append(vid)
-            spawn_lists += per_lane
-            starts = s.veh_start.astype(np.int64)  # ascending (creation order)
-            csum = np.concatenate([[0], np.cumsum(starts)])
-            idx = np.searchsorted(starts, np.arange(sim_len + 2), side="left")
-            created_cnt[si] = idx
-            created_tsum[si] = csum[idx]
-        spawn_ptr, spawn_vid = _csr(spawn_lists)
+            got = per_set.get(id(s))
+            if got is None:
+                first = route_first[s.veh_route] if s.n_veh else np.zeros(0, np.int64)
+                order = np.argsort(first, kind="stable").astype(np.int32)  # lane-major, creation order inside a lane
+                counts = np.bincount(first, minlength=nl).astype(np.int64)
+                starts = s.veh_start.astype(np.int64)  # ascending (creation order)
+                csum = np.concatenate([[0], np.cumsum(starts)])
+                idx = np.searchsorted(starts, np.arange(sim_len + 2), side="left")
+                got = per_set[id(s)] = (order, counts, idx.astype(np.int32), csum[idx])
+            spawn_vids.append(got[0])
+            spawn_cnt[si] = got[1]
+            created_cnt[si] = got[2]
+            created_tsum[si] = got[3]
+        spawn_ptr = np.zeros(len(sets) * nl + 1, dtype=np.int32)
+        spawn_ptr[1:] = np.cumsum(spawn_cnt.reshape(-1))
+        spawn_vid = cat(spawn_vids)
         self.flows = TscFlows(
             len(sets), sim_len, a(set_ptr, _pi), a(veh_route, _pi), a(veh_start, _pi),
             a(veh_tmpl, _pi), a(spawn_ptr, _pi), a(spawn_vid, _pi),

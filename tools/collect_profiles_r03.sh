@@ -42,7 +42,7 @@ configs)
   ;;
 sweep)
   # per-replica flow seeds ("seed = replica id for throughput runs"): what do the static per-set tables cost?
-  for fs in 8 64 512; do  # (4096 = one per replica would take the Python table builder ~10 min of host time per pass)
+  for fs in 8 64 512 4096; do  # (4096 = one set per replica; at most 64 distinct demands are generated and tiled: bench.py)
     pass fs${fs}_fetch FETCH_SIZE --family resident --steps 20 --warmup 5 --flow-sets $fs
   done
   ;;
