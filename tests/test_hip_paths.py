@@ -259,3 +259,38 @@ def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(or
         assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
     assert eng.errors() == 0 and orc.errors() == 0
     eng.close()
+
+
+def test_forced_paths_at_full_size_equal_the_default_paths():
+    """BASELINE config 1 size (4x4 @ 4096, 8 flow sets, per-replica action streams): a handle with every knob set
+    (two-phase hand-offs and the walk forced, a task list of 16) produces, for every one of the 4096 replicas, the
+    outputs of a default handle -- whose replicas tests/test_hip_fullsize_oracle.py links to the oracle at this size."""
+    import torch
+
+    import bench
+    from pytsc_amd.vec_env import VecEngine
+
+    R = 4096
+    want = ("obs", "mask", "stats", "local_reward64", "phase")
+    a = VecEngine(bench.workload_tables(4, 4, R, 0, 700.0, 8), want=want, family="resident")
+    tb = bench.workload_tables(4, 4, R, 0, 700.0, 8)
+    tb.cfg.resident_force = 3
+    tb.cfg.resident_task_capacity = 16
+    b = VecEngine(tb, want=want, family="resident")
+    acts = torch.empty((R, 16), device="cuda", dtype=torch.int32)
+    ba, bb = a.observe(), b.observe()
+    for s in range(70):
+        a.random_valid_actions(ba["mask"], seed=99, out=acts)
+        ba = a.step(acts)
+        bb = b.step(acts)
+        if s % 10 == 9:
+            for k in want:
+                assert torch.equal(ba[k], bb[k]), (s, k)
+    for r in (0, 1, 63, 2048, R - 1):
+        assert all(np.array_equal(x, y) for x, y in zip(a.snapshot(r), b.snapshot(r))), r
+    ca, cb = a.path_counts(), b.path_counts()
+    assert cb["two_phase"] == R * 70 * 5 and cb["walk"] == R * 71 and cb["serial_scan"] > 1000, cb  # (71: + the observe())
+    assert ca["walk"] == ca["dirty"] and ca["serial_scan"] == 0 and ca["two_phase"] == ca["conflict"] > 0, ca
+    assert a.errors() == 0 and b.errors() == 0
+    a.close()
+    b.close()
