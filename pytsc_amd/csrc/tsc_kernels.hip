@@ -1035,16 +1035,46 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
 }
 
 // ------------------------------------------------------------------ k_plan
-// One wave per list: turns the list's item count into batch descriptors (list, batch)
-// appended to the batch table.
-__global__ __launch_bounds__(64) void k_plan(DevNet N, DevState S) {
-  const int list = (int)blockIdx.x;
-  const int nb = (S.wl_cnt[list] + 63) >> 6;
-  if (nb == 0) return;
-  int base = 0;
-  if (threadIdx.x == 0) base = atomicAdd(&S.wl_nb[0], nb);
-  base = __builtin_amdgcn_readfirstlane(base);
-  for (int j = threadIdx.x; j < nb; j += 64) S.wl_desc[base + j] = make_int2(list, j);
+// Turns the lists' item counts into batch descriptors (list, batch) appended to the batch table.  One workgroup per
+// PLAN_LISTS lists: a block scan of their batch counts, ONE atomic add on the table's fill word per workgroup (one per
+// list was 25 k adds to one address on the 16x16 grid: the whole 137 us of the kernel), then the workgroup's descriptors
+// are written cooperatively, descriptor t by thread t mod PLAN_LISTS (its list found by bisection of the prefix sums in LDS).
+#define PLAN_LISTS 256
+__global__ __launch_bounds__(PLAN_LISTS) void k_plan(DevNet N, DevState S) {
+  __shared__ int pre[PLAN_LISTS + 1];
+  __shared__ int wsum[PLAN_LISTS / 64];
+  __shared__ int base_s;
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int list0 = (int)blockIdx.x * PLAN_LISTS, list = list0 + tid;
+  const int nb = list < S.n_lists ? (S.wl_cnt[list] + 63) >> 6 : 0;
+  int x = nb; // inclusive scan inside the wavefront
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  int off = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < PLAN_LISTS / 64; i++) {
+    if (i < w) off += wsum[i];
+    total += wsum[i];
+  }
+  pre[tid] = off + x - nb;
+  if (tid == 0) {
+    pre[PLAN_LISTS] = total;
+    base_s = total ? atomicAdd(&S.wl_nb[0], total) : 0;
+  }
+  __syncthreads();
+  const int base = base_s;
+  for (int t = tid; t < total; t += PLAN_LISTS) {
+    int lo = 0; // the last list whose first descriptor is not beyond t
+#pragma unroll
+    for (int st = PLAN_LISTS / 2; st; st >>= 1)
+      if (pre[lo + st] <= t) lo += st;
+    S.wl_desc[base + t] = make_int2(list0 + lo, t - pre[lo]);
+  }
 }
 
 // ------------------------------------------------------------------ k_exec
