@@ -93,6 +93,7 @@ struct DevNet {
   GP<int> lane_bins, lane_static;
   GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane
   GP<int> link_start_lane, link_end_lane, link_type, link_agent, link_local;
+  GP<int2> link_lane_local; // per lane-link: position of its start lane among its intersection's incoming lanes, of its end lane among the outgoing ones
   GP<uint32_t> link_avail_mask;
   GP<unsigned long long> link_conflict; // local-index mask of links crossing this link
   GP<unsigned long long> agent_phase_avail; // [n_agents*32]: local-index mask of links available in raw phase p

@@ -170,11 +170,13 @@ static inline int grid_for(int n_rb, int n_rowblk) { return ((n_rb + 7) / 8) * 8
 // notifyCross as three 64-bit masks; the exact
 // per-cross foe is resolved lazily by find_foe() only for occupied links.
 #define NOTIFY_WAVES 12
+#define NOTIFY_LANES 24 /* incoming / outgoing lanes of an intersection staged in LDS (more: direct loads) */
 // One workgroup = one intersection x 64 replicas: its waves split the intersection's
 // lane-links, each lane-link's three candidate bits are OR-ed in LDS, wave 0 writes
 // the masks (coalesced).
 __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState S, int n_rb, int n_agents) {
   __shared__ unsigned long long m_e[64], m_v[64], m_s[64];
+  __shared__ int s_a[2 * NOTIFY_LANES][64], s_b[2 * NOTIFY_LANES][64]; // lane words: count, {aux of the head | previous drivable of the tail}
   int rb, a;
   const bool live = map_block(n_rb, n_agents, rb, a);
   a = __builtin_amdgcn_readfirstlane(a);
@@ -189,6 +191,25 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
     m_s[lx] = 0;
     if (mine && a == 0) S.t[r] += 1; // the step index being executed from here on
   }
+  // the words of the intersection's lanes are read ONCE per workgroup into LDS (three lane-links share a start lane, three
+  // an end lane: reading them per lane-link was 180 rows of 256 bytes per workgroup, this is 84) -- this kernel is bound by
+  // exactly these reads
+  const int ib = N.agent_inc_ptr[a], n_inc = N.agent_inc_ptr[a + 1] - ib;
+  const int ob = N.agent_out_ptr[a], n_out = N.agent_out_ptr[a + 1] - ob;
+  const bool staged = n_inc <= NOTIFY_LANES && n_out <= NOTIFY_LANES; // (uniform; else: the direct loads below)
+  if (mine && staged) {
+    for (int j = wy; j < n_inc + n_out; j += NOTIFY_WAVES) {
+      if (j < n_inc) {
+        const int sl = N.agent_inc_lanes[ib + j];
+        s_a[j][lx] = S.cnt[IDX(sl)];
+        s_b[j][lx] = S.ab[SIDX(N.drv_slot_base[sl])].x;
+      } else {
+        const int e = N.agent_out_lanes[ob + j - n_inc];
+        s_a[NOTIFY_LANES + j - n_inc][lx] = S.cnt[IDX(e)];
+        s_b[NOTIFY_LANES + j - n_inc][lx] = S.tail_prev[IDX(e)];
+      }
+    }
+  }
   __syncthreads();
   if (mine) {
     unsigned long long oe = 0, ov = 0, os = 0;
@@ -197,14 +218,22 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
       const int link = N.agent_links[li];
       const int k = link - N.n_lanes;
       const unsigned long long bit = 1ull << (li - lb);
-      const int e = N.link_end_lane[k];
-      const int sl = N.link_start_lane[k];
-      // independent loads, issued together
       const int cl = S.cnt[IDX(link)];
-      const int he = S.cnt[IDX(e)];
-      const int tpv = S.tail_prev[IDX(e)];
-      const int hs = S.cnt[IDX(sl)];
-      const int ax = S.ab[SIDX(N.drv_slot_base[sl])].x;
+      int he, tpv, hs, ax;
+      if (staged) {
+        const int2 lo = N.link_lane_local[k]; // positions of its start / end lane among the intersection's lanes
+        hs = s_a[lo.x][lx];
+        ax = s_b[lo.x][lx];
+        he = s_a[NOTIFY_LANES + lo.y][lx];
+        tpv = s_b[NOTIFY_LANES + lo.y][lx];
+      } else {
+        const int e = N.link_end_lane[k];
+        const int sl = N.link_start_lane[k];
+        he = S.cnt[IDX(e)];
+        tpv = S.tail_prev[IDX(e)];
+        hs = S.cnt[IDX(sl)];
+        ax = S.ab[SIDX(N.drv_slot_base[sl])].x;
+      }
       if ((cl & TSC_CNT_MASK) > 0) ov |= bit;
       if ((he & TSC_CNT_MASK) > 0 && !(he & TSC_NEW_BIT) && tpv == link) oe |= bit;
       if ((hs & TSC_CNT_MASK) > 0 && ax == link) os |= bit;
