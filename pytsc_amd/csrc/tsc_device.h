@@ -90,6 +90,7 @@ struct DevNet {
   GP<int> drv_cap, drv_slot_base;
   GP<int> lane_out_ptr, lane_out_links, lane_in_ptr, lane_in_links;
   GP<double> lane_len_pytsc;
+  GP<double> lane_slots; // lane_len_pytsc / veh_size_min_gap: the divisor of a lane's occupancy
   GP<int> lane_bins, lane_static;
   GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane
   GP<int> link_start_lane, link_end_lane, link_type, link_agent, link_local;
