@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 NAMES = {1: "load", 2: "links (scan)", 3: "links + actions", 10: "spawn of sub-step 0", 11: "classify + notify", 12: "stage A",
          13: "stage B + followers", 14: "commits + stage C", 15: "two-phase unlink", 16: "hand-offs + spawn", 20: "measure (scan)",
-         21: "measure", 22: "store + lane terms", 23: "signals + sums"}
+         21: "measure", 22: "store + lane terms", 23: "signals + sums", 30: "  (zeroing)", 31: "  (notify: lane-links)"}
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
     buf = eng.observe()
     for _ in range(args.preroll):
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
-    NW, EV = 12, 64
+    NW, EV = 12, 128
     out = (C.c_ulonglong * (2 * EV * NW))()
     eng.lib.tsc_debug_wave_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int32]
     eng.lib.tsc_debug_wave_trace(eng.h, out, len(out))  # drop the pre-roll
