@@ -80,7 +80,7 @@ def main():
     print(f"exec, per wave per env step: heavy chunks {out[11] / n:.0f} cycles (all waves), follower chunks {out[12] / n:.0f} "
           f"(16 waves; the phase lasts until the slowest wave is done)")
     print("agent sub-phases (wave 0): sums %.0f, stats+mask %.0f, obs row build %.0f, obs row store %.0f" % tuple(out[i] / n for i in (16, 17, 18, 19)))
-    print("stats sums (one wave): %.0f; wave 5 waits at the agent barrier: %.0f" % (out[28] / n, (out[30] - out[29]) / n))
+    print("stats sums (one wave): %.0f" % (out[28] / n))
     print("exec stages per env step: A + followers %.0f, B (tasks) %.0f, C (finish) %.0f" % tuple(out[i] / n for i in (20, 21, 22)))
     print("stage A, first heavy chunk, per env step: half A1 (leader/gap + car-following) %.0f, half A2 (signal + tasks) %.0f" % (out[23] / n, out[24] / n))
     for name, slot, parts in (("stage A1", 32, ("gathers", "leader + gap", "car-following")), ("stage A2", 36, ("signal gating", "tasks")),

@@ -11,7 +11,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 NAMES = {1: "load", 2: "links (scan)", 3: "links + actions", 10: "spawn of sub-step 0", 11: "classify + notify", 12: "stage A",
          13: "stage B + followers", 14: "commits + stage C", 15: "two-phase unlink", 16: "hand-offs + spawn", 20: "measure (scan)",
-         21: "measure", 22: "store + lane terms", 23: "signals + sums", 30: "  (zeroing)", 31: "  (notify: lane-links)"}
+         21: "measure", 22: "store + lane terms", 23: "signals + sums", 30: "  (zeroing)", 31: "  (notify: lane-links)",
+         32: "  (signal sums)", 33: "  (stats + mask)", 34: "  (obs row build)"}
 
 
 def main():
