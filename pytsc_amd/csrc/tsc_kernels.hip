@@ -115,10 +115,11 @@ __device__ __forceinline__ int reach_steps(double cur, double distance, double t
     return (int)ceil((target - cur) / acc / interval) + (int)ceil((distance - dut) / target / interval);
   }
 }
-// a = 0.5 / dF and ia = 0.5 / a of the follower's deceleration dF come from the template table
-__device__ __forceinline__ double no_collision_speed(double vL, double dL, double vF, double a, double ia, double gap,
+// a = 0.5 / dF and ia = 0.5 / a of the follower's deceleration dF come from the template table; lb = 0.5 vL^2 / dL, the
+// leader's braking distance, from the caller
+__device__ __forceinline__ double no_collision_speed(double vL, double dL, double lb, double vF, double a, double ia, double gap,
                                                      double interval, double targetGap) {
-  double c = vF * interval / 2 + targetGap - 0.5 * vL * vL / dL - gap;
+  double c = vF * interval / 2 + targetGap - lb - gap;
   double b = 0.5 * interval;
   if (b * b < 4 * a * c) return -100;
   double v1 = ia * (sqrt(b * b - 4 * a * c) - b);
@@ -127,10 +128,15 @@ __device__ __forceinline__ double no_collision_speed(double vL, double dL, doubl
 }
 __device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, double vL, const Tm &tl, double gap,
                                                    double interval) {
-  double s = no_collision_speed(vL, tl.maxNegAcc, speed, t.hA_max, t.iA_max, gap, interval, 0);
+  // the leader's braking distance at its maximal and at its usual deceleration: the same division when the two are equal
+  // (CityFlow's default vehicle: 4.5 both) -- with one template the test is wave-uniform and the second division is skipped
+  const double hv = 0.5 * vL * vL;
+  const double lb_max = hv / tl.maxNegAcc;
+  const double lb_usual = tl.usualNegAcc == tl.maxNegAcc ? lb_max : hv / tl.usualNegAcc;
+  double s = no_collision_speed(vL, tl.maxNegAcc, lb_max, speed, t.hA_max, t.iA_max, gap, interval, 0);
   double assumeDecel = 0, leaderSpeed = vL;
   if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
-  s = min2(s, no_collision_speed(vL, tl.usualNegAcc, speed, t.hA_usual, t.iA_usual, gap, interval, t.minGap));
+  s = min2(s, no_collision_speed(vL, tl.usualNegAcc, lb_usual, speed, t.hA_usual, t.iA_usual, gap, interval, t.minGap));
   s = min2(s, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) / t.hwden);
   return s;
 }
@@ -143,11 +149,9 @@ __device__ __forceinline__ double stop_before_speed(double speed, const Tm &t, d
   double bd = brake_distance_after_accel(speed, t, interval);
   if (bd < distance) return speed + t.maxPosAcc * interval;
   double takeInterval = 2 * distance / (speed + 1e-9) / interval;
-  if (takeInterval >= 1) {
-    return speed - speed / cvt_int(takeInterval);
-  } else {
-    return speed - speed / takeInterval;
-  }
+  // (one division for both cases: the divisor is (int)takeInterval as a double, or takeInterval itself)
+  const double den = takeInterval >= 1 ? (double)cvt_int(takeInterval) : takeInterval;
+  return speed - speed / den;
 }
 
 // XCD-aware block -> (replica block, row block) map: blocks b and b+8 share an
