@@ -133,10 +133,19 @@ __device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, do
   const double hv = 0.5 * vL * vL;
   const double lb_max = hv / tl.maxNegAcc;
   const double lb_usual = tl.usualNegAcc == tl.maxNegAcc ? lb_max : hv / tl.usualNegAcc;
-  double s = no_collision_speed(vL, tl.maxNegAcc, lb_max, speed, t.hA_max, t.iA_max, gap, interval, 0);
+  // The bound at the maximal deceleration (target gap 0) is never below the one at the usual deceleration (target gap
+  // minGap >= 0) when the two decelerations are equal, on the leader's side and on the follower's: the two evaluations then
+  // differ in the target gap alone, and every operation of no_collision_speed is monotone in it, rounding included -- so
+  // min(first, second) IS the second (tests/test_measure_fastpath.py checks it on the host).  With one vehicle template the
+  // test is wave-uniform and the first evaluation -- a square root and a division -- is skipped.
+  const bool same = tl.usualNegAcc == tl.maxNegAcc && t.usualNegAcc == t.maxNegAcc && t.minGap >= 0.0;
   double assumeDecel = 0, leaderSpeed = vL;
   if (speed > leaderSpeed) assumeDecel = speed - leaderSpeed;
-  s = min2(s, no_collision_speed(vL, tl.usualNegAcc, lb_usual, speed, t.hA_usual, t.iA_usual, gap, interval, t.minGap));
+  double s = no_collision_speed(vL, tl.usualNegAcc, lb_usual, speed, t.hA_usual, t.iA_usual, gap, interval, t.minGap);
+  if (!same) {
+    const double s_max = no_collision_speed(vL, tl.maxNegAcc, lb_max, speed, t.hA_max, t.iA_max, gap, interval, 0);
+    s = min2(s_max, s);
+  }
   s = min2(s, (gap + (leaderSpeed + assumeDecel / 2) * interval - speed * interval / 2) / t.hwden);
   return s;
 }

@@ -90,3 +90,35 @@ def test_speed_predicates_without_divisions():
             norm = 0.0 if s == 0.0 else round(s, 6) / mx
             assert (k == 0.0) == (norm == 0.0), (s, mx)
             assert (k >= K) == (norm >= 1.0), (s, mx)
+
+
+def _no_collision_speed(vL, dL, vF, dF, gap, interval, target_gap):
+    """pytsc_amd/csrc/tsc_kernels.hip::no_collision_speed, operation by operation (numpy f64, no fused operations)."""
+    a = 0.5 / dF
+    ia = 0.5 / a
+    lb = 0.5 * vL * vL / dL
+    c = vF * interval / 2 + target_gap - lb - gap
+    b = 0.5 * interval
+    with np.errstate(invalid="ignore"):
+        v1 = ia * (np.sqrt(b * b - 4 * a * c) - b)
+    v2 = 2 * vL - dL * interval + 2 * (gap - target_gap) / interval
+    out = np.where(v1 < v2, v1, v2)
+    return np.where(b * b < 4 * a * c, -100.0, out)
+
+
+def test_car_following_bound_at_maximal_deceleration_is_redundant_when_the_decelerations_are_equal():
+    """car_follow_speed skips the first of its two no_collision_speed evaluations when maxNegAcc == usualNegAcc for
+    leader and follower: min(first, second) must then be the second, bit for bit."""
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    for dec, min_gap, interval in ((4.5, 2.5, 1.0), (4.5, 0.0, 1.0), (3.0, 1.0, 0.5), (7.3, 2.5, 1.0), (4.5, 1e-9, 1.0)):
+        vL = rng.uniform(0.0, 20.0, n)
+        vF = rng.uniform(0.0, 20.0, n)
+        gap = np.concatenate([rng.uniform(-10.0, 200.0, n // 2), rng.uniform(-1e-3, 5.0, n - n // 2)])
+        for arr in (vL, vF):
+            arr[rng.integers(0, n, n // 20)] = 0.0
+        gap[rng.integers(0, n, n // 50)] = min_gap
+        first = _no_collision_speed(vL, dec, vF, dec, gap, interval, 0.0)
+        second = _no_collision_speed(vL, dec, vF, dec, gap, interval, min_gap)
+        both = np.where(first < second, first, second)  # min2(first, second)
+        assert np.array_equal(both, second)
