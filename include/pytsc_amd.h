@@ -372,6 +372,12 @@ int tsc_check_tables(const tsc_net_t *net, const tsc_flows_t *flows, const tsc_c
 /* The kernel family the handle runs (TSC_FAMILY_LIST / TSC_FAMILY_RESIDENT). */
 int tsc_kernel_family(tsc_handle_t h);
 
+/* Which instantiation of the resident family's kernel the handle launches: 0 -- the generic one (layout and vehicle
+ * constants from device tables), 1 -- layout-specialised (BASELINE configs 1, 3, 4 at their default capacity), 2 -- layout
+ * AND CityFlow's default vehicle as compile-time constants (the reference's trip generators write no other vehicle:
+ * pytsc/backends/cityflow/trip_generator.py:47-57).  Same results bit for bit; -1 for a handle on the list family. */
+int tsc_kernel_variant(tsc_handle_t h);
+
 /* Sizes derived from the tables. */
 int tsc_obs_size(tsc_handle_t h);
 int tsc_state_size(tsc_handle_t h);

@@ -17,7 +17,7 @@ SYMBOLS = (
     "tsc_abi_version", "tsc_create", "tsc_destroy", "tsc_reset", "tsc_step", "tsc_observe",
     "tsc_lane_detail", "tsc_snapshot", "tsc_errors", "tsc_mean_vehicles", "tsc_obs_size",
     "tsc_state_size", "tsc_n_actions", "tsc_profile_enable", "tsc_profile_read",
-    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_check_tables", "tsc_path_counts",
+    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_kernel_variant", "tsc_check_tables", "tsc_path_counts",
 )
 
 ERRORS = {-1: "TSC_EINVAL (bad argument / inconsistent tables)",
@@ -64,7 +64,7 @@ def load():
     lib.tsc_mean_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
     lib.tsc_profile_enable.argtypes = [vp, C.c_int]
     lib.tsc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
-    for f in ("tsc_obs_size", "tsc_state_size", "tsc_n_actions", "tsc_kernel_family"):
+    for f in ("tsc_obs_size", "tsc_state_size", "tsc_n_actions", "tsc_kernel_family", "tsc_kernel_variant"):
         getattr(lib, f).argtypes = [vp]
     lib.tsc_check_tables.argtypes = [C.POINTER(TscNet), C.POINTER(TscFlows), C.POINTER(TscConfig),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

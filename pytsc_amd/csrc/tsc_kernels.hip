@@ -55,8 +55,10 @@ struct Tm {
   double hA_max, iA_max, hA_usual, iA_usual, limit, hwden;
 };
 
-__device__ __forceinline__ Tm load_tm(const DevNet &N, int id) {
-  const double *p = N.tmpl + (size_t)id * TSC_DT_STRIDE;
+__device__ __forceinline__ Tm load_tm_p(const double *tbl, int id);
+__device__ __forceinline__ Tm load_tm(const DevNet &N, int id) { return load_tm_p((const double *)N.tmpl, id); }
+__device__ __forceinline__ Tm load_tm_p(const double *tbl, int id) {
+  const double *p = tbl + (size_t)id * TSC_DT_STRIDE;
   Tm t;
   t.len = p[TSC_T_LEN];
   t.maxPosAcc = p[TSC_T_MAXPOSACC];

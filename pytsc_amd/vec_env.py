@@ -82,6 +82,11 @@ class VecEngine:
         return {1: "list", 2: "resident"}[self.lib.tsc_kernel_family(self.h)]
 
     @property
+    def kernel_variant(self):
+        """Instantiation of the resident kernel the handle launches (include/pytsc_amd.h, tsc_kernel_variant)."""
+        return {-1: "list family", 0: "generic", 1: "layout", 2: "layout + default vehicle"}[self.lib.tsc_kernel_variant(self.h)]
+
+    @property
     def kernel_info(self):
         return self._kernel_infos[self.family]
 
