@@ -69,6 +69,14 @@ def test_4x4_r8192_linked_to_oracle(family, oracle_lib):
     _run_linked(oracle_lib, "syn_4x4", 8192, 80, snap_at=(80,), min_veh=600, family=family)
 
 
+def test_4x4_whole_simulated_hour_linked_to_oracle(oracle_lib):
+    """The reference's episode (pytsc/__init__.py:52-62: 720 env steps = one simulated hour) from the empty network to
+    `terminated`, 512 replicas on the resident family (the instantiation the bench runs): seven replicas against the
+    oracle at EVERY step -- through the filling of the network to ~1 900 vehicles per replica, where the record capacity,
+    the stage slots and the 16-bit times of that family are used most."""
+    _run_linked(oracle_lib, "syn_4x4", 512, 720, snap_at=(360, 720), min_veh=1500, family="resident")
+
+
 def test_16x16_r256_linked_to_oracle(oracle_lib):
     """BASELINE config 2's network (256 agents) with 256 replicas: four 64-replica blocks."""
     _run_linked(oracle_lib, "syn_16x16", 256, 80, snap_at=(80,), min_veh=2000, family="list", sim_length=900)
