@@ -374,8 +374,9 @@ int tsc_kernel_family(tsc_handle_t h);
 
 /* Which instantiation of the resident family's kernel the handle launches: 0 -- the generic one (layout and vehicle
  * constants from device tables), 1 -- layout-specialised (BASELINE configs 1, 3, 4 at their default capacity), 2 -- layout
- * AND CityFlow's default vehicle as compile-time constants (the reference's trip generators write no other vehicle:
- * pytsc/backends/cityflow/trip_generator.py:47-57).  Same results bit for bit; -1 for a handle on the list family. */
+ * AND a known vehicle as compile-time constants (the 4x4 grid with CityFlow's default vehicle -- the reference's trip
+ * generators write no other: pytsc/backends/cityflow/trip_generator.py:47-57; Jinan with the vehicle of the shipped
+ * real-world flow files).  Same results bit for bit; -1 for a handle on the list family. */
 int tsc_kernel_variant(tsc_handle_t h);
 
 /* Sizes derived from the tables. */

@@ -296,17 +296,19 @@ def test_forced_paths_at_full_size_equal_the_default_paths():
     b.close()
 
 
-def test_the_three_instantiations_of_kr_step_agree_at_full_size(monkeypatch):
-    """BASELINE config 1 size: the handle the bench runs launches kr_step with the 4x4 layout AND CityFlow's default
-    vehicle folded in at compile time (resident_alloc picks it when the template row is that vehicle's, bit for bit); with
-    PYTSC_AMD_NO_DEFVEH the layout-specialised instantiation reads the same constants from the device table, with
-    PYTSC_AMD_NO_SPEC the generic one reads the layout too.  Same outputs for every replica, same vehicles."""
+@pytest.mark.parametrize("scenario", ["grid", "jinan"])
+def test_the_three_instantiations_of_kr_step_agree_at_full_size(scenario, monkeypatch):
+    """BASELINE config 1 (4x4 @ 4096) and config 4 (Jinan, 2048 of its 8192 replicas): the handle the bench runs launches
+    kr_step with the network's layout AND its vehicle folded in at compile time (resident_alloc picks that instantiation when
+    the template row is the known vehicle's, bit for bit: the trip generators' default vehicle / the shipped real-world flow
+    files' one); with PYTSC_AMD_NO_DEFVEH the layout-specialised instantiation reads the same constants from the device
+    table, with PYTSC_AMD_NO_SPEC the generic one reads the layout too.  Same outputs for every replica, same vehicles."""
     import torch
 
     import bench
     from pytsc_amd.vec_env import VecEngine
 
-    R = 4096
+    R = 4096 if scenario == "grid" else 2048
     want = ("obs", "mask", "stats", "local_reward64", "phase")
     engines = []
     for env in ({}, {"PYTSC_AMD_NO_DEFVEH": "1"}, {"PYTSC_AMD_NO_SPEC": "1"}):
@@ -314,12 +316,13 @@ def test_the_three_instantiations_of_kr_step_agree_at_full_size(monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        engines.append(VecEngine(bench.workload_tables(4, 4, R, 0, 700.0, 8), want=want, family="resident"))
+        engines.append(VecEngine(bench.workload_tables(4, 4, R, 0, 700.0, 8, scenario=scenario), want=want, family="resident"))
     for k in ("PYTSC_AMD_NO_DEFVEH", "PYTSC_AMD_NO_SPEC"):
         monkeypatch.delenv(k, raising=False)
     a = engines[0]
     assert [e.kernel_variant for e in engines] == ["layout + default vehicle", "layout", "generic"]
-    acts = torch.empty((R, 16), device="cuda", dtype=torch.int32)
+    A = a.tables.n_agents
+    acts = torch.empty((R, A), device="cuda", dtype=torch.int32)
     bufs = [e.observe() for e in engines]
     for s in range(80):
         a.random_valid_actions(bufs[0]["mask"], seed=41, out=acts)
@@ -327,10 +330,11 @@ def test_the_three_instantiations_of_kr_step_agree_at_full_size(monkeypatch):
         if s % 10 == 9:
             for k in want:
                 assert torch.equal(bufs[0][k], bufs[1][k]) and torch.equal(bufs[0][k], bufs[2][k]), (s, k)
-    for r in (0, 1, 63, 2048, R - 1):
+    for r in (0, 1, 63, R // 2, R - 1):
         sa = a.snapshot(r)
         for e in engines[1:]:
             assert all(np.array_equal(x, y) for x, y in zip(sa, e.snapshot(r))), r
+    assert a.mean_vehicles() > 300
     for e in engines:
         assert e.errors() == 0
         e.close()
