@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/pytsc_amd.h"
 
 #define TSC_CNT_MASK 0x3fffffff
