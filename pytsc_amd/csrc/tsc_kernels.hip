@@ -1719,8 +1719,9 @@ __device__ __forceinline__ double lane_mean_speed(const DevState &S, int r, int 
   return n == 0 ? 0.0 : S.lane_sum[IDX(l)] / n;
 }
 __device__ __forceinline__ double lane_occupancy(const DevNet &N, const DevState &S, const DevCfg &C, int r, int l) {
-  double lane_length = N.lane_len_pytsc[l] / C.veh_size_min_gap;
-  return S.lane_n[IDX(l)] / lane_length;
+  // (lane_slots = lane_len_pytsc / veh_size_min_gap, the host's IEEE division: the same bits as dividing here, once per
+  //  lane and replica less)
+  return S.lane_n[IDX(l)] / N.lane_slots[l];
 }
 
 #define AGENT_WAVES 2
