@@ -36,7 +36,8 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X"
 DEFAULT_OUTPUTS = "obs,mask,local_reward,global_reward,done,terminated,stats"
-MAX_DISTINCT_DEMANDS = 64
+MAX_SEQUENTIAL_DEMANDS = 64  # up to here: one poisson_flows() call per set (the sets of rounds 1-3); beyond: the array generator
+MAX_TILED_DEMANDS = 64
 
 
 def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="grid"):
@@ -52,21 +53,35 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="
         return load_case("jinan_3_4_random", n_replicas=n_replicas)[4]
 
     hip = {"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0}
-    if n_sets > MAX_DISTINCT_DEMANDS:
-        # many flow sets (the --flow-sets sweep up to one per replica): generating a demand costs the host half a second,
-        # so at most 64 distinct demands are generated and stored n_sets / 64 times each -- every set still has its own
-        # copy of the per-set device tables (spawn queues, path table), which is what the sweep measures
-        from pytsc_amd.flows import poisson_flows
-        from pytsc_amd.grid import generate_grid
-        from pytsc_amd.roadnet import RoadNet
+    if n_sets > MAX_SEQUENTIAL_DEMANDS:
+        # One demand per replica ("seed = replica id for throughput runs"): every set its own Poisson draw,
+        # generated with arrays (pytsc_amd/flows.py::poisson_flow_sets; set g of a rank is demand `set_offset + g` of the
+        # job: ranks of a multi-GPU run hold different demands, a replica holds the same one whatever the sharding).  On
+        # networks whose walk routes cannot be enumerated (large grids) the per-vehicle generator tiles 64 demands instead.
+        hip.update(n_flow_sets_batch=n_sets, flow_set_base=set_offset)
+        cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
+        from pytsc_amd.flows import enumerate_walk_routes
+        from pytsc_amd.roadnet import load_roadnet
 
-        rn = RoadNet(generate_grid(rows, cols))
-        base = Config(f"syn_{rows}x{cols}").simulator
+        rn = load_roadnet(cfg)
+        if enumerate_walk_routes(rn) is not None:
+            tb = build_tables(cfg, n_replicas=n_replicas, roadnet=rn, set_offset=0)  # (set r of this rank <-> its replica r)
+            tb.distinct_demands = n_sets
+            return tb
+        from pytsc_amd.flows import poisson_flows
+
+        base = cfg.simulator
         horizon = int(base["sim_length"]) + int(base["initial_wait_time"])
-        distinct = [poisson_flows(rn, rate, horizon, seed=i) for i in range(MAX_DISTINCT_DEMANDS)]
-        hip = {"flow_entries": [distinct[i % MAX_DISTINCT_DEMANDS] for i in range(n_sets)]}
+        distinct = [poisson_flows(rn, rate, horizon, seed=i) for i in range(MAX_TILED_DEMANDS)]
+        hip = {"flow_entries": [distinct[(set_offset + i) % MAX_TILED_DEMANDS] for i in range(n_sets)]}
+        cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
+        tb = build_tables(cfg, n_replicas=n_replicas, roadnet=rn, set_offset=0)
+        tb.distinct_demands = min(n_sets, MAX_TILED_DEMANDS)
+        return tb
     cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
-    return build_tables(cfg, n_replicas=n_replicas, set_offset=set_offset)
+    tb = build_tables(cfg, n_replicas=n_replicas, set_offset=set_offset)
+    tb.distinct_demands = n_sets
+    return tb
 
 
 # ------------------------------------------------------------------ CPU baseline
@@ -326,29 +341,23 @@ def roofline_valu(kinfo, R, va):
         return None
     return {k: r[k] for k in ("kernel", "V_a", "valu_busy_frac", "active_lane_frac", "useful_valu_frac", "salu_per_valu",
                               "wait_frac", "lds_bank_conflict_ratio", "waves_per_simd", "how") if k in r} | {
-        "source": f"profiles/{kinfo['valu_file']}"}
+        "source": f"profiles/{kinfo['valu_file']}",
+        # hardware counters cannot be read from inside this process: a quotation of the committed separate --pmc pass,
+        # tied to this run by its state only (same kernel, same replicas, V_a within 10 %)
+        "observed_in_this_run": False}
 
 
-def hour(args):
-    """Sustained measurement over the reference's episode structure (pytsc/__init__.py:52-62,164-176;
-    backends/cityflow/simulator.py:20-30): one simulated hour = 720 env steps from an EMPTY network under the random
-    policy, then the restart of every replica.  Throughput per 60-step window (HIP events at the window boundaries), the
-    env step at which the handle left the resident family (if it did) and the share of replica-steps spent off it."""
+def run_hour(eng, R, A, acts, family_requested="auto", n_steps=720, win=60):
+    """One simulated hour (720 env steps) of every replica of `eng` from an EMPTY network under the random policy, then
+    the restart: throughput per 60-step window (HIP events at the window boundaries; the handle's state is whatever the
+    caller left -- this restarts every replica first).  Returns the figures as a dict."""
     import torch
 
-    from pytsc_amd.vec_env import VecEngine
-
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    R = args.replicas
-    tables = workload_tables(args.rows, args.cols, R, 0, args.rate, args.flow_sets, args.scenario)
-    A = tables.n_agents
-    eng = VecEngine(tables, device=0, want=tuple(args.outputs.split(",")), family=args.family)
-    acts = torch.empty((R, A), device=dev, dtype=torch.int32)
+    dev = eng.device
+    eng.reset()
     buf = eng.observe()
-    n_steps, win = 720, 60
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps // win + 2)]
-    fam_steps, left_at, vehicles = {"resident": 0, "list": 0}, None, []
+    fam_steps, left_at = {"resident": 0, "list": 0}, None
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for s in range(n_steps):
@@ -357,7 +366,7 @@ def hour(args):
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
         fam = eng.family  # (a host-side field: no synchronisation)
         fam_steps[fam] += 1
-        if fam != "resident" and left_at is None and args.family != "list":
+        if fam != "resident" and left_at is None and family_requested != "list":
             left_at = s
     ev[n_steps // win].record()
     eng.reset(buf["terminated"])  # the restart of the hour (every replica: sim_step == 3600)
@@ -365,33 +374,65 @@ def hour(args):
     ev[n_steps // win + 1].record()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    n_term = int(buf["terminated"].sum().item()) if "terminated" in buf else None
     windows = []
     for w in range(n_steps // win):
         ms = ev[w].elapsed_time(ev[w + 1])
         windows.append({"env_steps": [w * win, (w + 1) * win], "ms_per_step": ms / win, "value": R * A * win / (ms * 1e-3)})
-    restart_ms = ev[n_steps // win].elapsed_time(ev[n_steps // win + 1])
-    paths = eng.path_counts()
-    errors = eng.errors()
-    best = max(w["value"] for w in windows)
-    line = {
-        "metric": "sustained " + METRIC, "value": R * A * n_steps / elapsed, "unit": "agent-env-steps/s", "n_gpus": 1,
-        "steps": n_steps, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson {args.rate:g} veh/h per entry road, "
-                               f"{R} env replicas, {args.flow_sets} flow sets, random valid actions, one simulated hour from an "
-                               f"empty network + the restart", "replicas_per_gpu": R, "agents": A,
-                   "family_requested": args.family, "resident_capacity": int(eng.tables.cfg.resident_capacity) or "default"},
-        "elapsed_s": elapsed, "restart_ms": restart_ms, "windows": windows,
+    return {
+        "value": R * A * n_steps / elapsed, "elapsed_s": elapsed, "steps": n_steps,
+        "restart_ms": ev[n_steps // win].elapsed_time(ev[n_steps // win + 1]), "windows": windows,
         "left_resident_family_at_env_step": left_at,
-        "share_of_replica_steps_off_resident": fam_steps["list"] / n_steps if args.family != "list" else None,
-        "stalled_replicas": paths["stalled"], "device_errors": errors,
+        "share_of_replica_steps_off_resident": fam_steps["list"] / n_steps if family_requested != "list" else None,
+        "stalled_replicas": eng.path_counts()["stalled"], "device_errors": eng.errors(),
+        "mean_live_vehicles_per_replica_at_the_end": eng.mean_vehicles(),
+    }
+
+
+def hour(args):
+    """Sustained measurement over the reference's episode structure (pytsc/__init__.py:52-62,164-176;
+    backends/cityflow/simulator.py:20-30): one simulated hour = 720 env steps from an EMPTY network under the random
+    policy, then the restart of every replica.  Throughput per 60-step window, the env step at which the handle left the
+    resident family (if it did) and the share of replica-steps spent off it."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    R = args.replicas
+    n_sets = flow_sets_of(args)
+    tables = workload_tables(args.rows, args.cols, R, 0, args.rate, n_sets, args.scenario)
+    A = tables.n_agents
+    eng = VecEngine(tables, device=0, want=tuple(args.outputs.split(",")), family=args.family)
+    acts = torch.empty((R, A), device=dev, dtype=torch.int32)
+    h = run_hour(eng, R, A, acts, args.family)
+    windows = h["windows"]
+    line = {
+        "metric": "sustained " + METRIC, "value": h["value"], "unit": "agent-env-steps/s", "n_gpus": 1,
+        "steps": h["steps"], "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson {args.rate:g} veh/h per entry road, "
+                               f"{R} env replicas, {n_sets} flow sets ({getattr(tables, 'distinct_demands', n_sets)} distinct demands), "
+                               f"random valid actions, one simulated hour from an empty network + the restart",
+                   "replicas_per_gpu": R, "agents": A,
+                   "family_requested": args.family, "resident_capacity": int(eng.tables.cfg.resident_capacity) or "default"},
+        **{k: h[k] for k in ("elapsed_s", "restart_ms", "windows", "left_resident_family_at_env_step",
+                             "share_of_replica_steps_off_resident", "stalled_replicas", "device_errors",
+                             "mean_live_vehicles_per_replica_at_the_end")},
         "vs_filled_state": {"filled_window": "env steps 120-180 (what bench.py's default timed region starts from)",
-                            "value_filled": windows[2]["value"], "sustained_over_filled": (R * A * n_steps / elapsed) / windows[2]["value"],
-                            "best_window": best},
+                            "value_filled": windows[2]["value"], "sustained_over_filled": h["value"] / windows[2]["value"],
+                            "best_window": max(w["value"] for w in windows)},
     }
     print(json.dumps(line), flush=True)
     eng.close()
-    return 0
+    return 1 if (h["device_errors"] or h["stalled_replicas"]) else 0
+
+
+def flow_sets_of(args):
+    """--flow-sets 0 (the default): one demand per replica of this rank ("seed = replica id for throughput
+    runs"); the real-network scenario has the one flow file the reference ships."""
+    if args.scenario != "grid":
+        return 1
+    return args.replicas if args.flow_sets <= 0 else args.flow_sets
 
 
 def worker(args):
@@ -415,7 +456,8 @@ def worker(args):
 
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
-        tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, args.flow_sets, args.scenario)
+        n_sets = flow_sets_of(args)
+        tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, n_sets, args.scenario)
         A = tables.n_agents
         eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")), family=args.family)
     red_dev = dev if (world_size > 1 and not args.stub) else "cpu"
@@ -464,9 +506,10 @@ def worker(args):
     eng.profile(False)
     v1 = eng.mean_vehicles()
     errors = eng.errors()
+    stalled = 0 if args.stub else eng.path_counts()["stalled"]
     # ---- beside the contract's numbers (N = 1 only, outside the timed region): the spread of single steps, and the same
     #      measurement in the state the default command line times (V_a grows with the env steps under a random policy)
-    spread, other_state = None, None
+    spread, other_state, eight_sets, hour_state = None, None, None, None
     if world_size == 1 and not args.stub and not args.no_extras:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         for i in range(args.steps):
@@ -492,7 +535,34 @@ def worker(args):
             other_state = {"after_env_steps": n_env_steps, "steps": 20, "ms_per_step": dt / 20 * 1e3,
                            "value": R * A * 20 / dt, "V_a": 0.5 * (va0 + va1) / A,
                            "note": "the last 20 of the env steps the default command line (--warmup 20 --steps 240) times"}
-        errors += eng.errors()
+        errors = eng.errors()  # (cumulative since tsc_create: the last read stands for the whole run -- ADVICE r3)
+        stalled = eng.path_counts()["stalled"]
+        # ---- the same timed region on the 8 shared flow sets of rounds 1-3 (a labelled state, not `value`), and the
+        #      sustained hour on this handle (0.6 s of GPU time)
+        if args.scenario == "grid" and n_sets != 8 and not args.no_states:
+            eng8 = VecEngine(workload_tables(args.rows, args.cols, R, 0, args.rate, 8), device=local_rank,
+                             want=tuple(args.outputs.split(",")), family=args.family)
+            b8 = eng8.observe()
+            for _ in range(PREROLL_ENV_STEPS + args.warmup):
+                b8 = eng8.step(eng8.random_valid_actions(b8["mask"], seed=1234, out=acts))
+            torch.cuda.synchronize(dev)
+            va80 = eng8.mean_vehicles()
+            t8 = time.perf_counter()
+            for _ in range(args.steps):
+                b8 = eng8.step(eng8.random_valid_actions(b8["mask"], seed=1234, out=acts))
+            torch.cuda.synchronize(dev)
+            dt8 = time.perf_counter() - t8
+            eight_sets = {"after_env_steps": PREROLL_ENV_STEPS + args.warmup + args.steps, "steps": args.steps,
+                          "ms_per_step": dt8 / args.steps * 1e3, "value": R * A * args.steps / dt8,
+                          "V_a": 0.5 * (va80 + eng8.mean_vehicles()) / A, "flow_sets": 8,
+                          "note": "the same timed region with 8 flow sets shared by all replicas (the bench lines of rounds "
+                                  "1-3: per-set static tables stay L2-resident)", "device_errors": eng8.errors()}
+            errors += eight_sets["device_errors"]
+            eng8.close()
+        if args.scenario == "grid" and not args.no_states:
+            hour_state = run_hour(eng, R, A, acts, args.family)
+            errors = max(errors, hour_state["device_errors"])
+            stalled = hour_state["stalled_replicas"]
     total_units = sharding.sum_over_ranks(R * A * args.steps, device=red_dev)
     v_mean = sharding.sum_over_ranks(0.5 * (v0 + v1), device=red_dev) / world_size
     value = total_units / elapsed
@@ -525,23 +595,30 @@ def worker(args):
                 traffic_src = f"profiles/{kinfo['traffic_file']}: {tj.get('formula', '')} at V_a {tj['V_a']:.1f}"
                 if traffic > HBM_PEAK_GBS:  # cannot be: the counters over-count this access pattern
                     traffic, traffic_src = None, traffic_src + " (rejected: above peak)"
+        if args.stub:
+            workload_name = "stub, "
+        elif args.scenario == "jinan":
+            workload_name = f"Jinan 3x4 real network ({A} agents), its real flow file, {R} env replicas per GPU, "
+        else:
+            distinct = getattr(tables, "distinct_demands", n_sets)
+            workload_name = (f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson {args.rate:g} veh/h per entry road, "
+                             f"{n_sets} flow sets per GPU ({distinct} distinct demands" +
+                             (": one per replica, drawn from its global index" if n_sets == R and distinct == R else "") +
+                             f"), {R} env replicas per GPU, ")
         line = {
             "metric": METRIC if not args.stub else "STUB (launcher test)",
             "value": value, "unit": "agent-env-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub" if args.stub else "synthetic",
             "config": {
-                "workload": (f"Jinan 3x4 real network ({A} agents), its real flow file, {R} env replicas per GPU, "
-                             if args.scenario == "jinan" else
-                             f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson "
-                             f"{args.rate:g} veh/h per entry road, {args.flow_sets} flow sets, {R} env replicas per GPU, ") +
-                            f"phase_selection action space, random valid actions, "
-                            f"outputs {args.outputs}",
+                "workload": workload_name + f"phase_selection action space, random valid actions, outputs {args.outputs}",
                 "replicas_per_gpu": R, "agents": A, "sub_steps_per_env_step": 5,
                 "state": "filled" if pre_steps else "as-started",
                 "preroll_env_steps": pre_steps,
                 "mean_live_vehicles_per_replica": v_mean, "V_a": va, "device_errors": errors,
-                "kernel_family": kinfo.get("family"),
+                "stalled_replicas": stalled, "kernel_family": kinfo.get("family"),
+                "flow_sets_per_gpu": None if args.stub else n_sets,
+                "distinct_demands_per_gpu": None if args.stub else getattr(tables, "distinct_demands", n_sets),
             },
             "roofline": {
                 # the bound the contract names for this tier; the path is NOT bandwidth-bound (the step would take ~50 us
@@ -549,6 +626,11 @@ def worker(args):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": traffic_src,
+                # `achieved` and `avg_launch_us` are measured in this run (HIP events on the launch stream); `traffic` is a
+                # quotation of the committed separate --pmc passes, never a counter read by this process
+                "traffic_observed_in_this_run": False,
+                "bound_note": "contractual: HBM is the bound SURVEY.md 8(d) names for this tier; what limits the kernel is "
+                              "the length of its barrier-separated phases (roofline_valu, DESIGN.md 5)",
                 "kernel": kinfo.get("name"), "kernel_note": kinfo.get("note"),
                 "avg_launch_us": avg_launch_s * 1e6, "launches": k_n,
                 "bytes_per_agent_env_step": bytes_per_unit, "V_a": va,
@@ -556,12 +638,25 @@ def worker(args):
         }
         if spread is not None:
             line["ms_per_step_spread"] = spread
+        states = [{"after_env_steps": pre_steps + args.warmup + args.steps, "steps": args.steps, "ms_per_step": ms_per_step,
+                   "value": value, "V_a": va, "note": "the timed region (value)"}]
         if other_state is not None:
-            line["states"] = [
-                {"after_env_steps": pre_steps + args.warmup + args.steps, "steps": args.steps, "ms_per_step": ms_per_step,
-                 "value": value, "V_a": va, "note": "the timed region (value)"},
-                other_state,
-            ]
+            states.append(other_state)
+        if eight_sets is not None:
+            states.append(eight_sets)
+        if hour_state is not None:
+            w = hour_state["windows"]
+            states.append({"after_env_steps": 720, "steps": 720, "ms_per_step": hour_state["elapsed_s"] / 720 * 1e3,
+                           "value": hour_state["value"], "note": "SUSTAINED: one simulated hour (720 env steps) from an empty "
+                           "network + the restart of every replica, on this handle right after the timed region "
+                           "(pytsc/__init__.py:52-62,164-176)",
+                           "last_window_value": w[-1]["value"], "best_window_value": max(x["value"] for x in w),
+                           "windows_M": [round(x["value"] / 1e6, 2) for x in w],
+                           "left_resident_family_at_env_step": hour_state["left_resident_family_at_env_step"],
+                           "share_of_replica_steps_off_resident": hour_state["share_of_replica_steps_off_resident"],
+                           "mean_live_vehicles_per_replica_at_the_end": hour_state["mean_live_vehicles_per_replica_at_the_end"]})
+        if len(states) > 1:
+            line["states"] = states
         line["roofline_valu"] = roofline_valu(kinfo, R, va)
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
@@ -572,6 +667,9 @@ def worker(args):
 
         dist.barrier()
         dist.destroy_process_group()
+    if errors or stalled:  # a stalled replica returns early: such a run measures less work than it claims
+        sys.stderr.write(f"bench.py: rank {rank}: device errors {errors}, stalled replicas {stalled}: the run is invalid\n")
+        return 1
     return 0
 
 
@@ -584,12 +682,15 @@ def parse(argv):
     ap.add_argument("--rows", type=int, default=4)
     ap.add_argument("--cols", type=int, default=4)
     ap.add_argument("--rate", type=float, default=700.0, help="veh/h per entry road")
-    ap.add_argument("--flow-sets", type=int, default=8)
+    ap.add_argument("--flow-sets", type=int, default=0,
+                    help="flow sets per GPU; 0 (default) = one demand per replica (SURVEY.md 8(d): seed = replica id for "
+                         "throughput runs); 8 = the shared sets of the bench lines of rounds 1-3")
     ap.add_argument("--scenario", default="grid", help="grid (rows x cols, Poisson demand) | jinan (BASELINE config 4)")
     ap.add_argument("--family", default="auto", help="kernel family: auto | list | resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-preroll", action="store_true", help="diagnostic: time the network as started")
-    ap.add_argument("--no-extras", action="store_true", help="skip the per-step spread and the second state (N = 1 extras)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-step spread and the other states (N = 1 extras)")
+    ap.add_argument("--no-states", action="store_true", help="skip the 8-flow-set state and the sustained hour (N = 1 extras)")
     ap.add_argument("--hour", action="store_true",
                     help="sustained measurement: one simulated hour (720 env steps) from an empty network, then the restart")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds per CPU-baseline leg")

@@ -34,7 +34,10 @@
  * copied at create time; `stream` is a hipStream_t passed as void* (NULL = the
  * null stream); every call returns 0 on success or a negative TSC_E* code and
  * never blocks the host except tsc_create/tsc_destroy/tsc_snapshot/tsc_errors.
- * No internal host threads; one handle per GPU.
+ * No internal host threads; one handle per GPU; a handle is driven from ONE
+ * stream at a time (its launch constants -- among them the output pointers of
+ * the step in flight -- are updated in the order of that stream: a caller that
+ * changes stream synchronises the old one first).
  *
  * The same table structs are consumed by the CPU oracle (oracle/tsc_oracle.h),
  * which is test infrastructure only.
@@ -48,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TSC_ABI_VERSION 3
+#define TSC_ABI_VERSION 4
 
 /* error codes */
 #define TSC_OK 0
@@ -95,15 +98,16 @@ extern "C" {
  *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the
  *             tables do not fit it.
  *   AUTO      RESIDENT where it fits, else LIST.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
- *             logs resets / actions on the device: when a replica comes within resident_margin (256) vehicle records of
+ *             logs resets / actions on the device: when a replica comes within resident_margin vehicle records of
  *             its capacity the handle moves to LIST by replaying the log (same results).  The flag travels to the host
  *             behind every step and is read, without synchronising, by the next tsc_step; a caller that enqueues steps
  *             without waiting is held back so that it never runs more than 16 steps ahead of the flag.  Should a replica
  *             run out of records all the same (more than the margin gained within those steps), it STALLS: its state
- *             stays that of its last completed step and its outputs stay those of that step until the migration, whose
- *             replay repairs everything -- the state after the migration is exact and tsc_errors stays 0 (the log holds
- *             1024 env steps and 64 partial restarts since the last full restart; beyond that there is no way back and
- *             an overflow raises the error counter).  A full restart (tsc_reset / tsc_reset_sets with no mask or with a mask that selects every
+ *             stays that of its last completed step, its rows in the output buffers are not written (valid_dev[r] = 0
+ *             tells the caller which replicas) until the migration, whose replay repairs everything -- the state after
+ *             the migration is exact and tsc_errors stays 0 (the log holds 1024 env steps and 64 partial restarts since
+ *             the last full restart; beyond that there is no way back and a stall raises the error counter, as it does
+ *             on a handle forced to RESIDENT).  A full restart (tsc_reset / tsc_reset_sets with no mask or with a mask that selects every
  *             replica) starts the log afresh and takes a migrated handle back to RESIDENT; to tell, such a handle
  *             copies the mask to the host and synchronises the stream (restarts are rare).  A handle forced to
  *             RESIDENT has no stand-by: a spawn that finds no free record raises the error counter (tsc_errors). */
@@ -244,7 +248,9 @@ typedef struct tsc_config {
   int32_t resident_task_capacity;/* (vehicle, cross) tasks per sub-step held on chip, 1..768 (0 = 768); a vehicle whose
                                   * tasks do not fit scans its crosses serially */
   int32_t resident_margin;       /* AUTO handles: records of headroom below which a replica asks for the migration to
-                                  * the list family (0 = 256) */
+                                  * the list family.  0 = derived at create from the flow sets: the most vehicles any
+                                  * set creates within the 16 env steps the host may run ahead of the flag, + 25 % for
+                                  * the stage slots of the heavy vehicles among them, + 64 */
 } tsc_config_t;
 
 /* Optional outputs of tsc_step; any pointer may be NULL (skipped). */
@@ -261,6 +267,11 @@ typedef struct tsc_step_out {
   int32_t *phase_dev;        /* [R, A, 3] current index, time_on_phase, phase_changed */
   double *local_reward64_dev;/* [R, A]  f64 copies for parity checks              */
   double *global_reward64_dev;/* [R] */
+  uint8_t *valid_dev;        /* [R]  1: every output row of this replica is that of the step (or observation) just
+                              * executed -- the reference never hands out anything else (pytsc/__init__.py:178-182);
+                              * 0: the replica is STALLED (resident family, out of vehicle records: see TSC_FAMILY_AUTO
+                              * above) -- its rows in the other buffers were not written by this call and still hold its
+                              * last completed step.  Always 1 on the list family. */
 } tsc_step_out_t;
 
 typedef struct tsc_env *tsc_handle_t;

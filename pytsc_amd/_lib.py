@@ -10,7 +10,8 @@ import os
 from pytsc_amd.tables import TscConfig, TscFlows, TscNet, TscStepOut
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpytsc_amd.so")
+# (PYTSC_AMD_LIB: another build of the same library -- same-box A/B of kernel variants, tools/ab_bench.py)
+LIB_PATH = os.environ.get("PYTSC_AMD_LIB") or os.path.join(HERE, "lib", "libpytsc_amd.so")
 
 # every symbol include/pytsc_amd.h declares
 SYMBOLS = (
@@ -68,7 +69,7 @@ def load():
         getattr(lib, f).argtypes = [vp]
     lib.tsc_check_tables.argtypes = [C.POINTER(TscNet), C.POINTER(TscFlows), C.POINTER(TscConfig),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    if lib.tsc_abi_version() != 3:
+    if lib.tsc_abi_version() != 4:
         raise RuntimeError("libpytsc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -5,18 +5,26 @@ import logging
 import numpy as np
 
 log = logging.getLogger("pytsc_amd")
-if not log.handlers:
-    _h = logging.StreamHandler()
+if not log.hasHandlers():  # (hasHandlers also sees the root logger's: an application that configured logging gets each
+    _h = logging.StreamHandler()  # message once, through its own handlers -- ADVICE r3)
     _h.setFormatter(logging.Formatter("%(asctime)s - %(levelname)s - %(message)s"))
     log.addHandler(_h)
-    log.setLevel(logging.INFO)
+    log.propagate = False
+log.setLevel(logging.INFO)
+
+
+def _get_logger(name=None, level=None):
+    """The package logger; a level, when given, is set -- as the reference's get_logger does on first use."""
+    if level is not None:
+        log.setLevel(level)
+    return log
 
 
 class EnvLogger:
     """Name kept for callers of the reference's helper (EnvLogger.set_log_level(logging.WARNING) is how its users
     silence the config dump); everything goes to the package logger `pytsc_amd`."""
 
-    get_logger = staticmethod(lambda name=None, level=None: log)
+    get_logger = staticmethod(_get_logger)
     log_info = staticmethod(log.info)
     log_warning = staticmethod(log.warning)
     set_log_level = staticmethod(log.setLevel)

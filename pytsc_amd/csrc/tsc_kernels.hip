@@ -53,7 +53,26 @@ struct Tm {
   double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
   // derived per template at create (same f64 operations, host side): see TSC_DT_* in tsc_device.h
   double hA_max, iA_max, hA_usual, iA_usual, limit, hwden;
+  // Divisors known at compile time (the vehicle-specialised instantiations of kr_step, -DR_CDIV): their correctly rounded
+  // reciprocals, and whether div_c may use them (false everywhere else: the test folds away)
+  bool cd = false;
+  double r_maxNegAcc = 0, r_usualNegAcc = 0, r_maxSpeed = 0, r_turnSpeed = 0;
 };
+
+// a / b, correctly rounded, for a divisor whose correctly rounded reciprocal rb = RN(1 / b) is at hand (a compile-time
+// constant in the callers): q0 = RN(a rb) is within 2 ulp of a / b; one Newton step on the exact residual (fma) makes it
+// faithful; Markstein's theorem (IBM J. R&D 34, 1990: y = RN(1 / b), q faithful, r = a - b q exact => RN(q + r y) = RN(a / b),
+// for every b whose significand is not all ones) makes the second step's result THE correctly rounded quotient -- the
+// number the hardware's v_div_scale / v_rcp / v_fma ... v_div_fixup sequence delivers, in five dependent operations
+// instead of about twelve.  Valid away from overflow / underflow of the residuals (|a| in [1e-290, 1e290] or a = +0: the
+// callers divide squared speeds and distances) -- tests/test_divconst.py checks it against the division on the host.
+__device__ __forceinline__ double div_c(double a, double b, double rb) {
+  double q = a * rb;
+  double r = fma(-b, q, a);
+  q = fma(r, rb, q);
+  r = fma(-b, q, a);
+  return fma(r, rb, q);
+}
 
 __device__ __forceinline__ Tm load_tm_p(const double *tbl, int id);
 __device__ __forceinline__ Tm load_tm(const DevNet &N, int id) { return load_tm_p((const double *)N.tmpl, id); }
@@ -95,6 +114,7 @@ __device__ __forceinline__ int cvt_int(double x) {
 
 // ---------------------------------------------------------------- kinematics
 __device__ __forceinline__ double min_brake_distance(double speed, const Tm &t) {
+  if (t.cd) return div_c(0.5 * speed * speed, t.maxNegAcc, t.r_maxNegAcc);
   return 0.5 * speed * speed / t.maxNegAcc;
 }
 __device__ __forceinline__ bool can_yield(double speed, const Tm &t, double dist) {
@@ -133,7 +153,7 @@ __device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, do
   // the leader's braking distance at its maximal and at its usual deceleration: the same division when the two are equal
   // (CityFlow's default vehicle: 4.5 both) -- with one template the test is wave-uniform and the second division is skipped
   const double hv = 0.5 * vL * vL;
-  const double lb_max = hv / tl.maxNegAcc;
+  const double lb_max = tl.cd ? div_c(hv, tl.maxNegAcc, tl.r_maxNegAcc) : hv / tl.maxNegAcc;
   const double lb_usual = tl.usualNegAcc == tl.maxNegAcc ? lb_max : hv / tl.usualNegAcc;
   // The bound at the maximal deceleration (target gap 0) is never below the one at the usual deceleration (target gap
   // minGap >= 0) when the two decelerations are equal, on the leader's side and on the follower's: the two evaluations then
@@ -154,6 +174,7 @@ __device__ __forceinline__ double car_follow_speed(double speed, const Tm &t, do
 // distance covered by one more acceleration step followed by usual braking to a stop
 __device__ __forceinline__ double brake_distance_after_accel(double speed, const Tm &t, double interval) {
   double nextSpeed = speed + t.maxPosAcc * interval;
+  if (t.cd) return (speed + nextSpeed) * interval / 2 + (div_c(nextSpeed * nextSpeed, t.usualNegAcc, t.r_usualNegAcc) / 2);
   return (speed + nextSpeed) * interval / 2 + (nextSpeed * nextSpeed / t.usualNegAcc / 2);
 }
 __device__ __forceinline__ double stop_before_speed(double speed, const Tm &t, double distance, double interval) {
@@ -2053,6 +2074,7 @@ __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
   }
   if (out.done_dev) out.done_dev[r] = (unsigned char)(sim_step > 0 && sim_step % C.episode_limit == 0);
   if (out.terminated_dev) out.terminated_dev[r] = (unsigned char)(sim_step == C.sim_length);
+  if (out.valid_dev) out.valid_dev[r] = 1; // (this family holds every drivable bumper to bumper: no replica ever stalls)
 }
 
 // --------------------------------------------------------------- k_snapshot

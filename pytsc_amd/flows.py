@@ -307,6 +307,89 @@ def poisson_flows(rn, rate_veh_per_hour=700.0, horizon=3600, seed=0,
     return flows
 
 
+def enumerate_walk_routes(rn, turn_probs=(0.1, 0.3, 0.6), max_len=None, limit=200000):
+    """Every route `random_walk_route` can return from each boundary-in road, with the probability it returns it (the
+    walk re-draws a route of one road or of more than max_len roads, so the probabilities of the accepted ones are
+    renormalised).  {road: ([route tuples], probabilities)}; None when there are more than `limit` routes (large grids:
+    the number grows exponentially with the diameter)."""
+    inc, out = fringe_roads(rn)
+    conn, out_set = _road_turns(rn), set(out)
+    if max_len is None:
+        max_len = _graph_diameter(rn) + 2
+    turns = ("turn_left", "turn_right", "go_straight")
+    table, total = {}, 0
+    for start in inc:
+        routes, probs = [], []
+        stack = [((start,), 1.0)]
+        while stack:
+            route, p = stack.pop()
+            cands = [(conn.get(route[-1], {}).get(t), turn_probs[i]) for i, t in enumerate(turns)]
+            cands = [(n, w) for n, w in cands if n is not None and n not in route]
+            tot = sum(w for _, w in cands)
+            if not cands or tot == 0:  # dead end: the walk stops here
+                if 1 < len(route) <= max_len:
+                    routes.append(route)
+                    probs.append(p)
+                continue
+            for n, w in cands:
+                r2 = route + (n,)
+                if n in out_set:
+                    if len(r2) <= max_len:
+                        routes.append(r2)
+                        probs.append(p * w / tot)
+                elif len(r2) <= max_len:
+                    stack.append((r2, p * w / tot))
+        total += len(routes)
+        if total > limit:
+            return None
+        pr = np.asarray(probs, dtype=np.float64)
+        table[start] = (routes, pr / pr.sum())
+    return table
+
+
+def poisson_flow_sets(fc, rate_veh_per_hour, horizon, set_ids, base_seed=0, turn_probs=(0.1, 0.3, 0.6), vehicle=None):
+    """Many Poisson demands at once, straight into FlowCompiler `fc` (one FlowSet per entry of `set_ids`): the process of
+    `poisson_flows` -- exponential inter-arrival times per boundary-in road, integer start second, a random-walk route
+    per vehicle -- drawn with numpy arrays instead of a Python loop per vehicle: the routes of a road come from the
+    enumerated walk distribution (`enumerate_walk_routes`), the arrivals of a set from one generator seeded with
+    (base_seed, set id), so that set g is the same demand whichever batch -- or rank -- generates it.  Not the stream of
+    `poisson_flows(seed=g)`: the same distribution, other draws.  Returns False (nothing added) when the network's walk
+    routes cannot be enumerated (large grids)."""
+    rn = fc.rn
+    table = enumerate_walk_routes(rn, turn_probs)
+    if table is None:
+        return False
+    vehicle = dict(DEFAULT_VEHICLE if vehicle is None else vehicle)
+    tid = fc._tmpl_id(vehicle)
+    inc, _ = fringe_roads(rn)
+    rids, cums = [], []
+    for road in inc:
+        routes, pr = table[road]
+        rids.append(np.asarray([fc._route_id(list(r)) for r in routes], dtype=np.int32))
+        cums.append(np.cumsum(pr))
+    mean = 3600.0 / rate_veh_per_hour
+    lam = horizon / mean
+    K = int(lam + 10.0 * np.sqrt(lam) + 32)
+    n_roads = len(inc)
+    for g in set_ids:
+        rng = np.random.default_rng([int(base_seed), int(g)])
+        t = np.cumsum(rng.exponential(mean, size=(n_roads, K)), axis=1)
+        u = rng.random((n_roads, K))
+        ok = t < horizon
+        if ok[:, -1].any():
+            raise RuntimeError("poisson_flow_sets: arrival buffer too short")
+        route = np.empty((n_roads, K), dtype=np.int32)
+        for i in range(n_roads):
+            k = np.minimum(np.searchsorted(cums[i], u[i], side="right"), len(rids[i]) - 1)
+            route[i] = rids[i][k]
+        st = t[ok].astype(np.int64)  # road-major, ascending within a road: the order poisson_flows appends in
+        order = np.argsort(st, kind="stable")  # ... and its stable sort by start second
+        n = len(order)
+        fs = FlowSet(route[ok][order], st[order], np.full(n, tid, np.int32), np.arange(n, dtype=np.int32), np.zeros(n, np.int32))
+        fc.sets.append(fs)
+    return True
+
+
 # --------------------------------------------------------------------------
 # compact on-disk form of a flow file (fixtures / generated scenarios)
 # --------------------------------------------------------------------------

@@ -35,8 +35,20 @@ def build_tables(config, n_replicas=None, roadnet=None, set_offset=0):
     parser = NetworkParser(config, roadnet=rn)
     fc = FlowCompiler(rn, interval=float(config.simulator["interval"]))
     horizon = int(config.simulator["sim_length"]) + int(config.simulator["initial_wait_time"])
-    for entries in flow_entry_sets(config, rn):
-        fc.add(entries, horizon)
+    sim = config.simulator
+    batch = int(sim.get("n_flow_sets_batch", 0) or 0)
+    done = False
+    if batch > 0 and config.synthetic_grid is not None and "flow_entries" not in sim:
+        # many distinct synthetic demands (one per replica in throughput runs): the array generator; set g of
+        # the batch is demand `flow_set_base + g`, whatever the batch (ranks of a multi-GPU run generate their own shards)
+        from pytsc_amd.flows import poisson_flow_sets
+
+        base = int(sim.get("flow_set_base", 0))
+        done = poisson_flow_sets(fc, float(sim.get("flow_rate", 700.0)), horizon, range(base, base + batch),
+                                 base_seed=int(sim.get("flow_seed", sim["seed"])))
+    if not done:
+        for entries in flow_entry_sets(config, rn):
+            fc.add(entries, horizon)
     if n_replicas is None:
         n_replicas = int(config.simulator.get("n_replicas", 1))
     return Tables(parser, fc, config, n_replicas, set_offset=set_offset)

@@ -72,7 +72,7 @@ class TscStepOut(C.Structure):
         ("done_dev", C.c_void_p), ("terminated_dev", C.c_void_p),
         ("stats_dev", C.c_void_p), ("agent_stats_dev", C.c_void_p),
         ("phase_dev", C.c_void_p), ("local_reward64_dev", C.c_void_p),
-        ("global_reward64_dev", C.c_void_p),
+        ("global_reward64_dev", C.c_void_p), ("valid_dev", C.c_void_p),
     ]
 
 

@@ -23,7 +23,7 @@ class VecEngine:
 
     def __init__(self, tables, device=0, want=("obs", "state", "mask", "local_reward", "global_reward",
                                               "done", "terminated", "stats", "agent_stats", "phase",
-                                              "local_reward64", "global_reward64"), family="auto"):
+                                              "local_reward64", "global_reward64", "valid"), family="auto"):
         if not torch.cuda.is_available():
             raise RuntimeError("pytsc_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _lib.load()
@@ -67,13 +67,15 @@ class VecEngine:
             "phase": ((R, A, 3), torch.int32),
             "local_reward64": ((R, A), torch.float64),
             "global_reward64": ((R,), torch.float64),
+            # 1: the replica's rows are those of the call just made; 0: it is stalled (include/pytsc_amd.h, valid_dev)
+            "valid": ((R,), torch.uint8),
         }
         self.buf = {k: z(*shapes[k]) for k in want}
         ptr = lambda k: self.buf[k].data_ptr() if k in self.buf else None
         self.out = TscStepOut(ptr("obs"), ptr("state"), ptr("mask"), ptr("local_reward"),
                               ptr("global_reward"), ptr("done"), ptr("terminated"), ptr("stats"),
                               ptr("agent_stats"), ptr("phase"), ptr("local_reward64"),
-                              ptr("global_reward64"))
+                              ptr("global_reward64"), ptr("valid"))
 
     @property
     def family(self):
@@ -218,7 +220,7 @@ class VecTrafficSignalNetwork:
 
     def __init__(self, scenario, simulator_backend="hip", n_replicas=1024, device=0, set_offset=0,
                  outputs=("obs", "state", "mask", "local_reward", "global_reward", "done", "terminated",
-                          "stats"), **kwargs):
+                          "stats", "valid"), **kwargs):
         from pytsc_amd.config import Config
         from pytsc_amd.scenario import build_tables
 
@@ -316,6 +318,12 @@ class VecTrafficSignalNetwork:
 
     def get_action_mask(self):
         return self.buf["mask"]
+
+    def get_valid(self):
+        """[R] uint8: 1 where the rows of the last step() / restart() are that call's; 0 for a replica that has run out of
+        vehicle records on the resident family and waits for the migration (its rows are those of its last completed
+        step).  The reference never returns a stale observation (pytsc/__init__.py:178-182): mask these replicas out."""
+        return self.buf["valid"]
 
     def get_reward(self):
         return self.buf["global_reward"]

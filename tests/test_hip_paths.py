@@ -241,23 +241,68 @@ def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(or
     eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_margin=1, **kw), family="auto")
     acts_dev = torch.tensor(np.stack(acts_all), device="cuda")
     torch.cuda.synchronize()
-    got, fam = [], []
+    got, fam, valid = [], [], []
     for s in range(steps):
         buf = eng.step(acts_dev[s])
         got.append(buf["obs"].clone())
+        valid.append(buf["valid"].clone())
         fam.append(eng.family)  # (host-side field: no synchronisation)
     torch.cuda.synchronize()
     assert fam[-1] == "list"
     first_list = fam.index("list")
     c = eng.path_counts()
     assert c["stalled"] >= 1, c
-    for s in range(first_list, steps):  # the step that migrated and all later ones
-        assert np.array_equal(got[s].cpu().numpy(), exp[s]), s
-    wrong = [s for s in range(first_list) if not np.array_equal(got[s].cpu().numpy(), exp[s])]
-    assert all(first_list - s <= 17 for s in wrong), (wrong, first_list)  # stale outputs only inside the run-ahead window
+    # The caller is told which rows are stale (the reference never returns a stale observation,
+    # pytsc/__init__.py:178-182): a replica's rows equal the oracle's wherever valid == 1 -- every replica, every step --,
+    # valid == 0 exactly for the stalled replicas, only inside the run-ahead window before the migration, and a row that
+    # differs from the oracle's is always marked
+    n_stale_rows = 0
+    for s in range(steps):
+        g, v = got[s].cpu().numpy(), valid[s].cpu().numpy()
+        for r in range(R):
+            same = np.array_equal(g[r], exp[s][r])
+            assert same or v[r] == 0, (s, r)
+            if v[r] == 0:
+                n_stale_rows += 1
+                assert s < first_list and first_list - s <= 17, (s, r, first_list)
+    assert n_stale_rows >= 1
+    assert all(int(v.min()) == 1 for v in valid[first_list:])  # (the list family never stalls)
     for r in range(R):
         assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
     assert eng.errors() == 0 and orc.errors() == 0
+    eng.close()
+
+
+def test_forced_resident_handle_that_runs_out_of_records_reports_an_error(oracle_lib):
+    """a handle FORCED to the resident family has nothing to migrate to.  When one of its replicas runs
+    out of records -- by the spawn that finds none, or by `live + heavy items > capacity` in the stall check behind the
+    classification -- it stalls for good: tsc_errors counts it, valid says which replica, the others stay exact."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(flow_rate=1800.0, n_flow_sets=2, sim_length=1500, episode_limit=500)
+    R, steps = 4, 270
+    orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
+    rng = np.random.default_rng(22)
+    out = orc.observe()
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, **kw), family="resident")
+    stalled = np.zeros(R, bool)
+    for s in range(steps):
+        m = out.mask
+        acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        out = orc.step(acts)
+        buf = eng.step(torch.tensor(acts, device="cuda"))
+        v = buf["valid"].cpu().numpy().astype(bool)
+        assert not (stalled & v).any()  # (a stalled replica of such a handle never comes back)
+        stalled |= ~v
+        g = buf["obs"].cpu().numpy()
+        for r in range(R):
+            if v[r]:
+                assert np.array_equal(g[r], out.obs[r]), (s, r)
+    assert stalled.any(), stalled
+    assert eng.path_counts()["stalled"] == int(stalled.sum())
+    assert eng.errors() >= int(stalled.sum())
     eng.close()
 
 
