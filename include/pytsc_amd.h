@@ -296,6 +296,13 @@ int tsc_reset(tsc_handle_t h, const uint8_t *reset_mask_dev, void *stream);
 int tsc_reset_sets(tsc_handle_t h, const uint8_t *reset_mask_dev,
                    const int32_t *set_index_dev, void *stream);
 
+/* Park the replicas with park_mask_dev[r] != 0: from now on tsc_step / tsc_observe skip them (their rows are not written,
+ * valid_dev[r] = 0) until a tsc_reset / tsc_reset_sets that selects them starts them again from an empty network.  What
+ * a batched multi-map environment needs (reference wrappers/epymarl.py:112-336 draws one of several maps at every
+ * simulated-hour restart: with one handle per map, a slot's replicas in the maps it is not playing are parked and cost
+ * a workgroup launch each).  Resident family only (TSC_EUNSUP on the list family, which steps every replica). */
+int tsc_park(tsc_handle_t h, const uint8_t *park_mask_dev, void *stream);
+
 /* One env step for all replicas: apply actions_dev[R, A], advance delta_time
  * engine sub-steps, measure, and fill the requested outputs.  An action of -1
  * leaves that signal untouched (phase and time_on_phase), as when the reference

@@ -25,12 +25,13 @@ class TrafficSignalNetwork:
     def __init__(self, scenario, simulator_backend="hip", **kwargs):
         if simulator_backend not in SUPPORTED_SIMULATOR_BACKENDS:
             raise AssertionError(f"Simulator backend {simulator_backend} not supported.")
-        if kwargs.get("disrupted", False):
-            raise NotImplementedError("disrupted (domain-randomised) configs are out of scope")
+        # domain-randomised demand (pytsc/__init__.py:21-30): the registry's `disrupted_config` instead of `config`
+        self.disrupted = kwargs.get("disrupted", False)
+        self.domain_class = kwargs.get("domain_class", None)
         factory = kwargs.pop("engine_factory", None)
         self.scenario, self.simulator_backend = scenario, simulator_backend
         self._mod = SIMULATOR_MODULES[simulator_backend]
-        self.config = self._mod["config"](scenario, **kwargs)
+        self.config = self._mod["disrupted_config" if self.disrupted else "config"](scenario, **kwargs)
         self._validate_config()
         self.parsed_network = self._mod["network_parser"](self.config)
         self.simulator = self._mod["simulator"](self.parsed_network, engine_factory=factory)
@@ -112,6 +113,9 @@ class TrafficSignalNetwork:
         info = self.metrics.get_step_stats()
         info["episode_count"] = self.episode_count
         info["episode_limit"] = self.episode_limit
+        if self.disrupted:  # (pytsc/__init__.py:153-155)
+            info["n_domains"] = len(self.config.domain_classes)
+            info["domain_class"] = self.config.current_domain_class
         return info
 
     def get_env_stats(self):
@@ -135,7 +139,11 @@ class TrafficSignalNetwork:
         self.hour_count += 1
         self.simulator.close_simulator()
         if reset:
-            self._boot()
+            self.simulator.start_simulator()
+            if self.domain_class is not None:  # (pytsc/__init__.py:173-174: after the start, so it binds the NEXT one)
+                self.config.set_domain_class(self.domain_class)
+            self._init_traffic_signals()
+            self._init_parsers()
 
     def close(self):
         self.simulator.shutdown()

@@ -53,7 +53,7 @@ struct Tm {
   double len, maxPosAcc, maxNegAcc, usualNegAcc, minGap, maxSpeed, headway, yieldDist, turnSpeed, approach;
   // derived per template at create (same f64 operations, host side): see TSC_DT_* in tsc_device.h
   double hA_max, iA_max, hA_usual, iA_usual, limit, hwden;
-  // Divisors known at compile time (the vehicle-specialised instantiations of kr_step, -DR_CDIV): their correctly rounded
+  // Divisors known at compile time (the vehicle-specialised instantiations of kr_step): their correctly rounded
   // reciprocals, and whether div_c may use them (false everywhere else: the test folds away)
   bool cd = false;
   double r_maxNegAcc = 0, r_usualNegAcc = 0, r_maxSpeed = 0, r_turnSpeed = 0;

@@ -122,6 +122,13 @@ class VecEngine:
         self._last_reset_args = (mask, sets)  # keep alive until the kernels have run
         _lib.check(self.lib.tsc_reset_sets(self.h, m, s, self._stream()), "tsc_reset_sets")
 
+    def park(self, mask):
+        """Replicas with mask[r] != 0 are skipped by every later step / observe (valid = 0) until a reset that selects them
+        (include/pytsc_amd.h, tsc_park; resident family only)."""
+        mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._last_park = mask
+        _lib.check(self.lib.tsc_park(self.h, C.c_void_p(mask.data_ptr()), self._stream()), "tsc_park")
+
     def observe(self):
         _lib.check(self.lib.tsc_observe(self.h, C.byref(self.out), self._stream()), "tsc_observe")
         return self.buf
@@ -221,10 +228,13 @@ class VecTrafficSignalNetwork:
     def __init__(self, scenario, simulator_backend="hip", n_replicas=1024, device=0, set_offset=0,
                  outputs=("obs", "state", "mask", "local_reward", "global_reward", "done", "terminated",
                           "stats", "valid"), **kwargs):
-        from pytsc_amd.config import Config
+        from pytsc_amd.config import Config, DisruptedConfig
         from pytsc_amd.scenario import build_tables
 
-        self.config = Config(scenario, **kwargs)
+        # domain-randomised demand (reference pytsc/__init__.py:21-30): every file of the mode is a flow set of the tables,
+        # each (re)started replica draws its own (domain, disruption value, file) -- DisruptedConfig.draw_sets
+        self.disrupted = bool(kwargs.get("disrupted", False))
+        self.config = DisruptedConfig(scenario, **kwargs) if self.disrupted else Config(scenario, **kwargs)
         sig = self.config.signal
         self.obs_kind = sig.get("observation_space", "position_matrix")
         if self.obs_kind not in ("position_matrix", "lane_features"):
@@ -252,6 +262,13 @@ class VecTrafficSignalNetwork:
         self._drop_rng = torch.Generator(device=self.engine.device).manual_seed(int(self.config.simulator["seed"]) + 1)
         self._keep = None  # [R, A, state_size] 0/1 multiplier of the lane-feature observation (lane dropout)
         self._dropped = None
+        self.current_domain_class = None  # [R] int64 (disrupted configs): index into config.domain_classes
+        if self.disrupted:
+            sets, cls = self.config.draw_sets(n_replicas, self._set_rng)
+            self.engine.reset(sets=sets)
+            self.buf = self.engine.observe()
+            self.current_domain_class = cls.to(self.engine.device)
+            self.current_sets = sets.clone()  # [R] int32 (host): the flow set = file of config.simulator["flow_files"] each replica runs
         if self.obs_kind == "lane_features":
             self._lane_slot = self._lane_slots()
             self.reset_dropped_lanes()
@@ -336,6 +353,9 @@ class VecTrafficSignalNetwork:
         st = self.buf["stats"]
         info = {k: st[:, i] for i, k in enumerate(STAT_KEYS)}
         info["episode_limit"] = self.episode_limit
+        if self.disrupted:  # (pytsc/__init__.py:153-155, per replica)
+            info["n_domains"] = len(self.config.domain_classes)
+            info["domain_class"] = self.current_domain_class
         return info
 
     def step(self, actions):
@@ -349,7 +369,12 @@ class VecTrafficSignalNetwork:
         describe the fresh state afterwards.  `flow_rate_type: random` draws a flow set per
         restarted replica (backends/cityflow/config.py:63-76), here from a seeded torch generator."""
         sets = None
-        if self.config.simulator.get("flow_rate_type", "constant") == "random" and self.tables.flows.n_sets > 1:
+        if self.disrupted:
+            sets, cls = self.config.draw_sets(self.n_replicas, self._set_rng)
+            over = self.buf["terminated"].to(torch.bool)
+            self.current_domain_class = torch.where(over, cls.to(over.device), self.current_domain_class)
+            self.current_sets = torch.where(over.cpu(), sets, self.current_sets)
+        elif self.config.simulator.get("flow_rate_type", "constant") == "random" and self.tables.flows.n_sets > 1:
             sets = torch.randint(0, int(self.tables.flows.n_sets), (self.n_replicas,), generator=self._set_rng,
                                  dtype=torch.int32)
         self.engine.reset(self.buf["terminated"], sets=sets)

@@ -49,6 +49,12 @@ class EPyMARLTrafficSignalNetwork(MultiAgentEnv):
     def apply_actions(self, actions):
         self.tsc_env.action_space.apply(actions)
 
+    def get_domain_class(self):
+        return self.tsc_env.config.domain_class
+
+    def set_domain_class(self, domain_class):
+        self.tsc_env.config.set_domain_class(domain_class)
+
     def get_env_info(self):
         env, space = self.tsc_env, self.tsc_env.observation_space
         return dict(

@@ -1,0 +1,138 @@
+"""`disrupted_config` of the backend registry (reference pytsc/backends/cityflow/__init__.py:18-26,
+backends/cityflow/config.py:106-175, selected at pytsc/__init__.py:26-30): the draws of the restatement against a fixture
+recorded from the reference's own class (tests/golden/gen_disrupted_golden.py), the vectorised draw of the batched
+environment, and the façade on top of it (CPU: the oracle engine stand-in)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from fixtures import GOLDEN
+
+FIX = os.path.join(GOLDEN, "disrupted_config", "expected.json")
+
+
+def _cfg(section, mode, seed, **kw):
+    from pytsc_amd.config import DisruptedConfig
+
+    return DisruptedConfig("syn_2x2", mode=mode, cityflow=dict(section, seed=seed), **kw)
+
+
+def test_registry_holds_the_reference_keys():
+    from pytsc_amd import SIMULATOR_MODULES
+    from pytsc_amd.config import Config, DisruptedConfig
+
+    keys = {"config", "disrupted_config", "network_parser", "simulator", "traffic_signal", "metrics_parser", "retriever"}
+    assert set(SIMULATOR_MODULES["hip"]) == keys  # = CITYFLOW_MODULES of the reference
+    assert SIMULATOR_MODULES["hip"]["disrupted_config"] is DisruptedConfig and issubclass(DisruptedConfig, Config)
+
+
+def test_draws_equal_the_reference_class():
+    fx = json.load(open(FIX))
+    for case in fx["cases"]:
+        kw = {}
+        if case["domain_class"] is not None:
+            kw["domain_class"] = tuple(case["domain_class"])
+        cfg = _cfg(fx["section"], case["mode"], case["seed"], **kw)
+        assert cfg.domains == case["domains"]
+        assert cfg.disrup_values == case["disrup_values"]
+        assert [list(c) for c in cfg.domain_classes] == case["domain_classes"]
+        assert cfg.current_domain_class is None
+        for i, (flow_file, cls) in enumerate(case["draws"]):
+            if case["set_domain_class_before_draw_6"] is not None and i == 6:
+                cfg.set_domain_class(tuple(case["set_domain_class_before_draw_6"]))
+            cfg._set_flow_file()
+            assert (cfg.flow_file, cfg.current_domain_class) == (flow_file, cls), (case["mode"], case["seed"], i)
+            # the file is one of the device tables' flow sets, owned by the class just drawn
+            k = cfg.simulator["flow_files"].index(cfg.flow_file)
+            assert cfg.file_domain_class[k] == cls
+
+
+def test_vectorised_draw_follows_the_three_level_law():
+    import torch
+
+    fx = json.load(open(FIX))
+    cfg = _cfg(fx["section"], "train", 0)
+    n = 200000
+    sets, cls = cfg.draw_sets(n, torch.Generator().manual_seed(5))
+    sets, cls = sets.numpy(), cls.numpy()
+    owner = np.asarray(cfg.file_domain_class)
+    assert np.array_equal(owner[sets], cls)  # a file of the class drawn
+    # uniform over domains, then over the domain's values, then over the class's files
+    p_cls = {c: 1.0 / len(cfg.domains) / len(cfg.disrup_values[d]) for c, (d, v) in enumerate(cfg.domain_classes)}
+    for c, p in p_cls.items():
+        assert abs((cls == c).mean() - p) < 4 * np.sqrt(p * (1 - p) / n)
+        files = np.flatnonzero(owner == c)
+        for f in files:
+            q = p / len(files)
+            assert abs((sets == f).mean() - q) < 4 * np.sqrt(q * (1 - q) / n) + 1e-4
+    cfg.set_domain_class(("link_disrupted", "0_3"))
+    sets, cls = cfg.draw_sets(1000, torch.Generator().manual_seed(6))
+    assert set(cls.tolist()) == {cfg.domain_classes.index(("link_disrupted", "0_3"))}
+    assert set(owner[sets.numpy()].tolist()) == set(cls.tolist())
+
+
+def _write_scenario(tmp_path):
+    """A 2x2 scenario directory in the reference's layout with a train section of two domains: the heavy and the light
+    demand differ visibly after a few steps."""
+    from pytsc_amd.flows import poisson_flows
+    from pytsc_amd.grid import generate_grid
+    from pytsc_amd.roadnet import RoadNet
+
+    rn = RoadNet(generate_grid(2, 2))
+    section = {"train": {"flow_disrupted": {"900": ["a.json", "b.json"], "300": ["c.json"]}, "link_disrupted": {"0_1": ["d.json"]}}}
+    rates = {"a.json": 900, "b.json": 900, "c.json": 300, "d.json": 600}
+    seed = 0
+    for d, vals in section["train"].items():
+        for v, files in vals.items():
+            os.makedirs(tmp_path / "train" / d / v, exist_ok=True)
+            for f in files:
+                seed += 1
+                with open(tmp_path / "train" / d / v / f, "w") as fh:
+                    json.dump(poisson_flows(rn, rates[f], 3600, seed=seed), fh)
+    return section
+
+
+def test_facade_restarts_on_the_drawn_file_and_reports_the_domain(tmp_path):
+    from oracle_engine import oracle_engine_factory
+
+    from pytsc_amd import TrafficSignalNetwork
+
+    section = _write_scenario(tmp_path)
+    kw = dict(engine_factory=oracle_engine_factory, disrupted=True, mode="train", scenario_dir=str(tmp_path),
+              cityflow=dict(section, seed=4, sim_length=60, episode_limit=30),
+              signal={"action_space": "phase_selection", "round_robin": False})
+    env = TrafficSignalNetwork("syn_2x2", "cityflow", **kw)
+    cfg = env.config
+    seen = []
+    for hour in range(6):
+        info = env.get_env_info()
+        assert info["n_domains"] == 3 and info["domain_class"] == cfg.current_domain_class
+        files = cfg.simulator["flow_files"]
+        k = files.index(cfg.flow_file)
+        assert cfg.file_domain_class[k] == cfg.current_domain_class
+        seen.append(cfg.flow_file)
+        # the engine runs the drawn file: vehicles created so far == that file's starts <= t
+        with open(os.path.join(str(tmp_path), cfg.flow_file)) as fh:
+            starts = np.asarray([e["startTime"] for e in json.load(fh)])
+        for s in range(12):
+            mask = np.asarray(env.get_action_mask())
+            _, done, info = env.step([int(np.flatnonzero(m)[0]) for m in mask])
+            if s == 1:  # 10 engine steps in: nobody has finished, (almost) everybody due has entered
+                due = int((starts < 10).sum())
+                assert due - 2 <= env.simulator.step_measurements["sim"]["n_vehicles"] <= due, (hour, cfg.flow_file)
+            if done:
+                env.restart()
+        assert env.simulator.n_starts == hour + 2  # (12 env steps = the 60-second "hour": restarted)
+    assert len(set(seen)) > 1
+    # a pinned domain class binds every start
+    env2 = TrafficSignalNetwork("syn_2x2", "cityflow", domain_class=("flow_disrupted", "300"), **kw)
+    for _ in range(3):
+        assert env2.config.flow_file.endswith(os.path.join("flow_disrupted", "300", "c.json"))
+        assert env2.get_env_info()["domain_class"] == env2.config.domain_classes.index(("flow_disrupted", "300"))
+        for s in range(12):
+            mask = np.asarray(env2.get_action_mask())
+            _, done, _ = env2.step([int(np.flatnonzero(m)[0]) for m in mask])
+            if done:
+                env2.restart()

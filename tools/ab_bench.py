@@ -23,7 +23,7 @@ def one(lib, steps, warmup, extra):
     _lib.LIB_PATH = os.path.abspath(lib)
     import bench
 
-    return bench.main(["--no-cpu-baseline", "--steps", str(steps), "--warmup", str(warmup)] + extra)
+    return bench.main(["--no-cpu-baseline", "--no-extras", "--steps", str(steps), "--warmup", str(warmup)] + extra)
 
 
 def main():
