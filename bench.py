@@ -53,6 +53,8 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="
         return load_case("jinan_3_4_random", n_replicas=n_replicas)[4]
 
     hip = {"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0}
+    if os.environ.get("PYTSC_AMD_SPILL_LIMIT"):  # diagnostic: -1 = an `auto` handle without the spill pool (A/B of its cost)
+        hip["resident_spill_limit"] = int(os.environ["PYTSC_AMD_SPILL_LIMIT"])
     if n_sets > MAX_SEQUENTIAL_DEMANDS:
         # One demand per replica ("seed = replica id for throughput runs"): every set its own Poisson draw,
         # generated with arrays (pytsc_amd/flows.py::poisson_flow_sets; set g of a rank is demand `set_offset + g` of the
@@ -228,7 +230,7 @@ def launch_workers(args, argv):
     HIP runtime (GPUs are counted from the KFD topology in sysfs).  The children are polled together: the first one that
     fails takes the others down at once (they would otherwise sit in the rendezvous until its timeout)."""
     n = args.gpus
-    if not args.stub:
+    if not args.stub and not args.one_gpu_rehearsal:
         have = count_gpus_without_hip()
         if have is not None and have < n:
             sys.stderr.write(f"bench.py: --gpus {n} requested but this node has {have} GPU(s)\n")
@@ -440,7 +442,9 @@ def worker(args):
 
     from pytsc_amd import sharding
 
-    rank, local_rank, world_size = sharding.init(backend="gloo" if args.stub else None)
+    rank, local_rank, world_size = sharding.init(backend="gloo" if (args.stub or args.one_gpu_rehearsal) else None)
+    if args.one_gpu_rehearsal:
+        local_rank = 0  # every rank on GPU 0: the N > 1 code path on one card (tests/test_hip_multirank.py), not a measurement
     if world_size != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}")
     cpu_line = None
@@ -458,16 +462,17 @@ def worker(args):
         torch.cuda.set_device(dev)
         n_sets = flow_sets_of(args)
         tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, n_sets, args.scenario)
+        tables.cfg.replica_base = rank * R  # the policy's draws follow the GLOBAL replica index, like the flow sets
         A = tables.n_agents
         eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")), family=args.family)
-    red_dev = dev if (world_size > 1 and not args.stub) else "cpu"
+    red_dev = dev if (world_size > 1 and not args.stub and not args.one_gpu_rehearsal) else "cpu"
     torch.manual_seed(0)
     buf = eng.observe()
     acts = torch.empty((R, A), device=dev, dtype=torch.int32)
 
     def policy(mask):
         # uniform among mask-valid actions, on device, one launch (tsc_random_valid_actions)
-        return eng.random_valid_actions(mask, seed=1234 + rank, out=acts)
+        return eng.random_valid_actions(mask, seed=1234, out=acts)
 
     n_env_steps = 0
 
@@ -507,6 +512,13 @@ def worker(args):
     v1 = eng.mean_vehicles()
     errors = eng.errors()
     stalled = 0 if args.stub else eng.path_counts()["stalled"]
+    if args.dump_state and not args.stub:
+        # what this rank's replicas look like right behind the timed region (tests: a sharded job == the unsharded one)
+        import numpy as np
+
+        np.savez(f"{args.dump_state}.rank{rank}.npz", rank=rank, replica_base=rank * R,
+                 stats=buf["stats"].cpu().numpy(), obs=buf["obs"].cpu().numpy(), mask=buf["mask"].cpu().numpy(),
+                 counts=eng.replica_counts().cpu().numpy())
     # ---- beside the contract's numbers (N = 1 only, outside the timed region): the spread of single steps, and the same
     #      measurement in the state the default command line times (V_a grows with the env steps under a random policy)
     spread, other_state, eight_sets, hour_state = None, None, None, None
@@ -697,6 +709,9 @@ def parse(argv):
     ap.add_argument("--cpu-warmup", type=int, default=150, help="untimed env steps of the CPU baseline")
     ap.add_argument("--outputs", default=DEFAULT_OUTPUTS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher test only
+    ap.add_argument("--one-gpu-rehearsal", action="store_true",
+                    help="tests: run the --gpus N code path with every rank on GPU 0 (gloo for the barrier / reductions)")
+    ap.add_argument("--dump-state", default=None, help="tests: write <path>.rank<k>.npz with each rank's outputs behind the timed region")
     return ap.parse_args(argv)
 
 

@@ -97,15 +97,21 @@ extern "C" {
  *             sub-steps and the measurement, ONE launch per env step; networks whose replica fits
  *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the
  *             tables do not fit it.
- *   AUTO      RESIDENT where it fits, else LIST.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
+ *   AUTO      RESIDENT where it fits, else LIST.  A replica of an AUTO handle on RESIDENT that comes within resident_margin
+ *             records of its capacity is PROMOTED to the handle's spill pool: its state is copied into a blob with room for
+ *             every drivable bumper to bumper (up to 16320 records) and the same kernel steps it from there with its
+ *             working image in global memory instead of LDS -- several times slower for that replica, bit-identical
+ *             results, the other replicas untouched.  Once more than resident_spill_limit replicas have asked, the whole
+ *             handle moves to LIST instead, as follows.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
  *             logs resets / actions on the device: when a replica comes within resident_margin vehicle records of
  *             its capacity the handle moves to LIST by replaying the log (same results).  The flag travels to the host
  *             behind every step and is read, without synchronising, by the next tsc_step; a caller that enqueues steps
  *             without waiting is held back so that it never runs more than 16 steps ahead of the flag.  Should a replica
  *             run out of records all the same (more than the margin gained within those steps), it STALLS: its state
  *             stays that of its last completed step, its rows in the output buffers are not written (valid_dev[r] = 0
- *             tells the caller which replicas) until the migration, whose replay repairs everything -- the state after
- *             the migration is exact and tsc_errors stays 0 (the log holds 1024 env steps and 64 partial restarts since
+ *             tells the caller which replicas) until the host gets to it: promoted, it is caught up from the actions of
+ *             the last 32 steps, which the handle keeps; or the migration's replay repairs everything -- either way the
+ *             state afterwards is exact and tsc_errors stays 0 (the log holds 1024 env steps and 64 partial restarts since
  *             the last full restart; beyond that there is no way back and a stall raises the error counter, as it does
  *             on a handle forced to RESIDENT).  A full restart (tsc_reset / tsc_reset_sets with no mask or with a mask that selects every
  *             replica) starts the log afresh and takes a migrated handle back to RESIDENT; to tell, such a handle
@@ -219,6 +225,14 @@ typedef struct tsc_flows {
   const int32_t *spawn_vid;      /*   vids waiting order (creation order)         */
   const int32_t *created_cnt;    /* [n_sets*(sim_len+2)] vehicles created at steps < t */
   const int64_t *created_tsum;   /* [n_sets*(sim_len+2)] sum of their creation times  */
+  /* Last tie-break of Cross::canPass (equal road-link types, equal steps to the cross, equal link-entry times, equal
+   * distances): CityFlow compares the vehicles' `priority`, drawn from the engine's std::mt19937(seed) when a vehicle is
+   * created.  NULL (the default): the lower vehicle id goes first -- the documented deviation of rounds 1-3.  Else
+   * [n vehicles, all sets] priorities, the HIGHER goes first (equal: the lower id): the host's restatement of that stream
+   * (pytsc_amd/flows.py::mt19937_priorities, config key `priority_rule: mt19937`) -- a hypothesis about an engine that is
+   * not here, kept behind this switch so that a recorded CityFlow trace can tell the two rules apart
+   * (tools/capture_cityflow_golden.py, tests/test_cityflow_pin.py). */
+  const int32_t *veh_priority;
 } tsc_flows_t;
 
 typedef struct tsc_config {
@@ -251,6 +265,22 @@ typedef struct tsc_config {
                                   * the list family.  0 = derived at create from the flow sets: the most vehicles any
                                   * set creates within the 16 env steps the host may run ahead of the flag, + 25 % for
                                   * the stage slots of the heavy vehicles among them, + 64 */
+  int32_t resident_spill_limit;  /* AUTO handles: most replicas the spill pool may hold -- a replica that asks for more room is
+                                  * promoted there one by one (TSC_FAMILY_AUTO above) -- before the whole handle moves to
+                                  * the list family instead.  0 = max(16, n_replicas / 8); -1 = no pool: whole-handle
+                                  * migration only (the behaviour of ABI 3) */
+  int32_t replica_base;          /* global index of this handle's replica 0 in a job sharded over several handles / GPUs:
+                                  * the counter-based draws (tsc_random_valid_actions, the observation noise) are keyed
+                                  * on replica_base + r, so a replica draws the same numbers whatever the sharding */
+  /* Observation noise on the device (reference common/observations.py:72-88, PositionMatrix._add_gaussian_noise): every
+   * surviving entry (> 0) of an incoming lane's position-matrix window gets val + N(0, std), clipped to [0, 1], BEFORE the
+   * integer truncation of the row (the entry ends as 1 iff val + noise >= 1); empty bins and stopped vehicles
+   * vanish as without noise (Q2) and take no draw.  The draws are a counter-based generator keyed on (seed, replica, engine
+   * step, signal, lane, ordinal of the surviving bin): reproducible, independent across replicas -- the law of the
+   * reference's noise, not numpy's stream (the single-env facade follows that one).  0 = off: rows bit for bit those of a
+   * handle without the fields.  Resident family only (TSC_EUNSUP on the list family). */
+  double obs_noise_std;
+  uint64_t obs_noise_seed;
 } tsc_config_t;
 
 /* Optional outputs of tsc_step; any pointer may be NULL (skipped). */
@@ -360,6 +390,11 @@ int tsc_errors(tsc_handle_t h, int32_t *n_errors);
  *  [5] replicas that ran out of records and stalled until the handle migrated */
 #define TSC_N_PATHS 8
 int tsc_path_counts(tsc_handle_t h, int64_t *counts);
+
+/* The spill pool of an AUTO handle on the resident family (synchronous with the HOST's view only: no device call):
+ * counts[4] int32 = (replicas living in the pool now, pool slots handed out since the last full restart, record capacity
+ * of a pool slot, resident_spill_limit in force); all 0 for a handle without a pool. */
+int tsc_spill_counts(tsc_handle_t h, int32_t *counts);
 
 /* Mean number of running vehicles per replica at the last measure pass
  * (synchronous; used for reporting V_a). */

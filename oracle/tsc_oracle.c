@@ -394,8 +394,16 @@ static int cross_can_pass(const orc_t *o, const rep_t *r, int vid, int link, int
         } else {
           if (v->enter_ll_time == foe->enter_ll_time) {
             if (d1 == d2) {
-              /* engine: random priority; here: lower vid has priority */
-              yield = vid < fv ? -1 : 1;
+              /* engine: the vehicles' random priorities (std::mt19937 of the config seed, drawn at creation); the
+               * tables either carry a restatement of that stream (tsc_flows_t::veh_priority: higher goes first) or
+               * none: lower vid goes first */
+              if (o->fl.veh_priority) {
+                const int base = o->fl.set_veh_ptr[r->set];
+                const int p1 = o->fl.veh_priority[base + vid], p2 = o->fl.veh_priority[base + fv];
+                yield = p1 != p2 ? (p1 > p2 ? -1 : 1) : (vid < fv ? -1 : 1);
+              } else {
+                yield = vid < fv ? -1 : 1;
+              }
             } else {
               yield = d1 < d2 ? -1 : 1;
             }

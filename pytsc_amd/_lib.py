@@ -18,7 +18,7 @@ SYMBOLS = (
     "tsc_abi_version", "tsc_create", "tsc_destroy", "tsc_reset", "tsc_step", "tsc_observe",
     "tsc_lane_detail", "tsc_snapshot", "tsc_errors", "tsc_mean_vehicles", "tsc_obs_size",
     "tsc_state_size", "tsc_n_actions", "tsc_profile_enable", "tsc_profile_read",
-    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_kernel_variant", "tsc_check_tables", "tsc_path_counts", "tsc_park",
+    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_kernel_variant", "tsc_check_tables", "tsc_path_counts", "tsc_park", "tsc_spill_counts",
 )
 
 ERRORS = {-1: "TSC_EINVAL (bad argument / inconsistent tables)",
@@ -54,7 +54,10 @@ def load():
     lib.tsc_reset.argtypes = [vp, vp, vp]
     lib.tsc_reset_sets.argtypes = [vp, vp, vp, vp]
     lib.tsc_replica_counts.argtypes = [vp, vp, vp]
-    lib.tsc_park.argtypes = [vp, vp, vp]
+    if hasattr(lib, "tsc_park"):  # (older builds of the library in a same-box A/B, tools/ab_bench.py, lack the newest entry points)
+        lib.tsc_park.argtypes = [vp, vp, vp]
+    if hasattr(lib, "tsc_spill_counts"):
+        lib.tsc_spill_counts.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.tsc_step.argtypes = [vp, vp, C.POINTER(TscStepOut), vp]
     lib.tsc_observe.argtypes = [vp, C.POINTER(TscStepOut), vp]
     lib.tsc_lane_detail.argtypes = [vp, vp, vp, vp, C.c_int32, vp]

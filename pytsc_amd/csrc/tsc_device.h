@@ -115,7 +115,17 @@ struct DevNet {
   int n_sets, sim_len;
   GP<int> set_veh_ptr, veh_route, veh_start, veh_tmpl, spawn_ptr, spawn_vid, created_cnt;
   GP<long long> created_tsum;
+  GP<int> veh_prio; // tsc_flows_t::veh_priority (null: the lower vehicle id goes first)
 };
+
+// last tie-break of Cross::canPass between vehicles `vid` and `fvid` of the flow set at `vbase`: true = `vid` goes first
+__device__ __forceinline__ bool tsc_goes_first(const DevNet &N, int vbase, int vid, int fvid) {
+  if (N.veh_prio) {
+    const int p1 = N.veh_prio[vbase + vid], p2 = N.veh_prio[vbase + fvid];
+    if (p1 != p2) return p1 > p2;
+  }
+  return vid < fvid;
+}
 
 struct DevState {
   int R, RS; // replicas, row stride (R rounded up to 64)
@@ -171,4 +181,8 @@ struct DevCfg {
   int r_task_cap; // cross tasks per sub-step held in LDS (<= R_TASKS); beyond: the vehicle scans its crosses serially
   int r_margin;   // records of headroom below which a replica asks for the migration to the list family
   double interval, veh_size_min_gap, flickering_coef;
+  // device-side observation noise (tsc_config_t::obs_noise_std / _seed; resident family): 0 = off
+  float obs_noise_std;
+  unsigned long long obs_noise_seed;
+  int replica_base; // tsc_config_t::replica_base: global index of replica 0 (keys of the counter-based draws)
 };

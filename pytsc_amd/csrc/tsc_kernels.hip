@@ -395,7 +395,7 @@ __device__ __forceinline__ bool cross_can_pass(const DevNet &N, const DevState &
           yield = 1;
         } else {
           if (ell == f.ell) {
-            if (d1 == d2) yield = vid < f.vid ? -1 : 1;
+            if (d1 == d2) yield = tsc_goes_first(N, N.set_veh_ptr[S.set[r]], vid, f.vid) ? -1 : 1;
             else yield = d1 < d2 ? -1 : 1;
           } else {
             yield = ell < f.ell ? -1 : 1;
@@ -1746,6 +1746,41 @@ __device__ __forceinline__ double lane_occupancy(const DevNet &N, const DevState
 }
 
 #define AGENT_WAVES 2
+// The 64 rows of one wavefront (replicas rb * 64 ..., signal a; bytes, value + 1, in LDS) -> rows of floats of [R, A, size].
+// Round 4: every lane stores FOUR floats per instruction (16 bytes, non-temporal: written once, not read by this library) and
+// the (row, position) pairs of the 64 rows are dealt to the lanes as one index space -- 64 x 81 float4 of the observation
+// rows are 81 store instructions per wavefront; a float per lane and one row at a time took 384 (the launch was bound by
+// store issue: 0.83 ms per env step on the 16x16 grid for 1.36 GB).  Same bytes in memory.
+__device__ __forceinline__ void agent_store_rows(const unsigned char *rows, int row_stride, float *out, int size, int rb, int a, int A,
+                                                 int R, int lx) {
+  const int n_rows = min(64, R - rb * 64);
+  if ((size & 3) == 0) {
+    typedef float a_f4 __attribute__((ext_vector_type(4)));
+    const int q = size >> 2; // float4 per row
+    int rr = lx / q, j4 = lx - rr * q;
+    while (rr < n_rows) {
+      const unsigned int w4 = *(const unsigned int *)(rows + (size_t)rr * row_stride + 4 * j4);
+      a_f4 v;
+      v.x = (float)((int)(w4 & 255u) - 1);
+      v.y = (float)((int)((w4 >> 8) & 255u) - 1);
+      v.z = (float)((int)((w4 >> 16) & 255u) - 1);
+      v.w = (float)((int)(w4 >> 24) - 1);
+      __builtin_nontemporal_store(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
+      j4 += 64;
+      while (j4 >= q) {
+        j4 -= q;
+        rr++;
+      }
+    }
+  } else {
+    for (int rr = 0; rr < n_rows; rr++) {
+      float *dst = out + ((size_t)(rb * 64 + rr) * A + a) * size;
+      const unsigned char *src = rows + (size_t)rr * row_stride;
+      for (int j = lx; j < size; j += 64) dst[j] = (float)((int)src[j] - 1);
+    }
+  }
+}
+
 // Per-agent statistics, observation / state vectors, action mask (reference
 // backends/cityflow/traffic_signal.py:101-141, common/observations.py:140-160,
 // 183-205, common/actions.py:119-131,169-188, common/traffic_signal.py:329-404).
@@ -1856,15 +1891,7 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
       for (int i = 0; i < TSC_MAX_PHASES; i++) row[w++] = i < np_ ? (i == cur ? 2 : 1) : 0;
     }
     __syncthreads();
-    if (live) {
-      for (int rr = 0; rr < 64; rr++) {
-        int r2 = rb * 64 + rr;
-        if (r2 >= S.R) break;
-        float *dst = out.obs_dev + ((size_t)r2 * A + a) * C.obs_size;
-        const unsigned char *src = rows_lds + ((size_t)wy * 64 + rr) * row_stride;
-        for (int j = lx; j < C.obs_size; j += 64) dst[j] = (float)((int)src[j] - 1);
-      }
-    }
+    if (live) agent_store_rows(rows_lds + (size_t)wy * 64 * row_stride, row_stride, out.obs_dev, C.obs_size, rb, a, A, S.R, lx);
     __syncthreads();
   }
   if (out.state_dev) {
@@ -1883,15 +1910,7 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
       for (int i = 0; i < TSC_MAX_PHASES; i++) row[w++] = (i < np_ && i == cur) ? 2 : 1;
     }
     __syncthreads();
-    if (live) {
-      for (int rr = 0; rr < 64; rr++) {
-        int r2 = rb * 64 + rr;
-        if (r2 >= S.R) break;
-        float *dst = out.state_dev + ((size_t)r2 * A + a) * C.state_size;
-        const unsigned char *src = rows_lds + ((size_t)wy * 64 + rr) * row_stride;
-        for (int j = lx; j < C.state_size; j += 64) dst[j] = (float)((int)src[j] - 1);
-      }
-    }
+    if (live) agent_store_rows(rows_lds + (size_t)wy * 64 * row_stride, row_stride, out.state_dev, C.state_size, rb, a, A, S.R, lx);
   }
 }
 
@@ -2108,8 +2127,9 @@ __global__ void k_random_valid(DevState S, DevCfg C, int A, const unsigned char 
   const unsigned char *m = mask + (size_t)i * C.n_actions;
   int allowed = 0;
   for (int k = 0; k < C.n_actions; k++) allowed += m[k] != 0;
-  // splitmix64 of (seed, draw index, replica * A + agent)
-  unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (draw + 1) + 0xbf58476d1ce4e5b9ull * (unsigned long long)(i + 1);
+  // splitmix64 of (seed, draw index, GLOBAL replica * A + agent): the same draw whatever the sharding (replica_base)
+  unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (draw + 1) +
+                         0xbf58476d1ce4e5b9ull * ((unsigned long long)C.replica_base * (unsigned long long)A + (unsigned long long)(i + 1));
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
   z ^= z >> 31;
@@ -2137,9 +2157,12 @@ __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total
 #include "tsc_resident.inc"
 
 // Action log of a handle that may migrate from the resident to the list family (tsc_api.inc): one byte per action.
-__global__ void k_log_actions(signed char *dst, const int *src, int n) {
+__global__ void k_log_actions(signed char *dst, signed char *dst2, const int *src, int n) { // (either destination may be null)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (signed char)src[i];
+  if (i >= n) return;
+  const signed char v = (signed char)src[i];
+  if (dst) dst[i] = v;
+  if (dst2) dst2[i] = v;
 }
 __global__ void k_unlog_actions(int *dst, const signed char *src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

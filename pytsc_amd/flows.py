@@ -307,6 +307,18 @@ def poisson_flows(rn, rate_veh_per_hour=700.0, horizon=3600, seed=0,
     return flows
 
 
+def mt19937_priorities(seed, n):
+    """CityFlow draws a vehicle's `priority` -- the last tie-break of Cross::canPass -- from the engine's
+    `std::mt19937 rnd` (seeded with the config `seed`, backends/cityflow/config.py:88-99) in the Vehicle constructor, i.e.
+    in creation order (step, flow index, count: the order of the vehicle ids here).  The C++ standard fixes that
+    generator bit for bit (10000th output of the default seed 5489: 4123659995); numpy's legacy seeding of an integer
+    seed is the same init_genrand and `random_raw` its 32-bit outputs.  Returned as the `int` the engine stores them in.
+    A HYPOTHESIS about an engine that is not here: if the engine's router draws first lanes from
+    the same generator the streams interleave differently -- which a recorded trace would show (tests/test_cityflow_pin.py)."""
+    raw = np.random.RandomState(int(seed) & 0xFFFFFFFF)._bit_generator.random_raw(int(n)) if n else np.zeros(0, np.uint64)
+    return raw.astype(np.uint32).view(np.int32).copy()
+
+
 def enumerate_walk_routes(rn, turn_probs=(0.1, 0.3, 0.6), max_len=None, limit=200000):
     """Every route `random_walk_route` can return from each boundary-in road, with the probability it returns it (the
     walk re-draws a route of one road or of more than max_len roads, so the probabilities of the accepted ones are

@@ -46,7 +46,7 @@ class TscFlows(C.Structure):
         ("n_sets", C.c_int32), ("sim_len", C.c_int32),
         ("set_veh_ptr", _pi), ("veh_route", _pi), ("veh_start", _pi), ("veh_tmpl", _pi),
         ("spawn_ptr", _pi), ("spawn_vid", _pi),
-        ("created_cnt", _pi), ("created_tsum", _pl),
+        ("created_cnt", _pi), ("created_tsum", _pl), ("veh_priority", _pi),
     ]
 
 
@@ -62,6 +62,8 @@ class TscConfig(C.Structure):
         ("kernel_family", C.c_int32), ("resident_capacity", C.c_int32),
         ("resident_threads", C.c_int32), ("resident_force", C.c_int32),
         ("resident_task_capacity", C.c_int32), ("resident_margin", C.c_int32),
+        ("resident_spill_limit", C.c_int32), ("replica_base", C.c_int32),
+        ("obs_noise_std", C.c_double), ("obs_noise_seed", C.c_uint64),
     ]
 
 
@@ -236,10 +238,20 @@ class Tables:
         spawn_ptr = np.zeros(len(sets) * nl + 1, dtype=np.int32)
         spawn_ptr[1:] = np.cumsum(spawn_cnt.reshape(-1))
         spawn_vid = cat(spawn_vids)
+        # the last tie-break of Cross::canPass (include/pytsc_amd.h, tsc_flows_t::veh_priority): lower vehicle id (default) or a
+        # restatement of the engine's mt19937 priority stream: every set is one engine run seeded with the config seed
+        rule = str(sim.get("priority_rule", "vid"))
+        if rule not in ("vid", "mt19937"):
+            raise ValueError(f"priority_rule {rule!r}: expected vid or mt19937")
+        prio = None
+        if rule == "mt19937":
+            from pytsc_amd.flows import mt19937_priorities
+
+            prio = a(cat([mt19937_priorities(int(sim["seed"]), s.n_veh) for s in sets]), _pi)
         self.flows = TscFlows(
             len(sets), sim_len, a(set_ptr, _pi), a(veh_route, _pi), a(veh_start, _pi),
             a(veh_tmpl, _pi), a(spawn_ptr, _pi), a(spawn_vid, _pi),
-            a(created_cnt.reshape(-1), _pi), a(created_tsum.reshape(-1), _pl),
+            a(created_cnt.reshape(-1), _pi), a(created_tsum.reshape(-1), _pl), prio,
         )
         self.max_veh = int(max([s.n_veh for s in sets] + [1]))
 
@@ -256,6 +268,8 @@ class Tables:
             int(sim.get("resident_capacity", 0)), int(sim.get("resident_threads", 0)),
             int(sim.get("resident_force", 0)), int(sim.get("resident_task_capacity", 0)),
             int(sim.get("resident_margin", 0)),
+            int(sim.get("resident_spill_limit", 0)), int(sim.get("replica_base", 0)),
+            0.0, 0,  # device-side observation noise: off (the batched environment turns it on, vec_env.py)
         )
         self.n_replicas = int(n_replicas)
         self.obs_size = MAX_CTRL_LANES * (int(sig["visibility"]) + LANE_STATIC) + MAX_PHASES

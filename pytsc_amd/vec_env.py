@@ -205,6 +205,12 @@ class VecEngine:
         _lib.check(self.lib.tsc_path_counts(self.h, c), "tsc_path_counts")
         return {k: int(c[i]) for i, k in enumerate(self.PATH_KEYS)}
 
+    def spill_counts(self):
+        """dict: the spill pool of an `auto` handle on the resident family (include/pytsc_amd.h, tsc_spill_counts)."""
+        c = (C.c_int32 * 4)()
+        _lib.check(self.lib.tsc_spill_counts(self.h, c), "tsc_spill_counts")
+        return dict(zip(("live", "slots", "capacity", "limit"), (int(x) for x in c)))
+
     def mean_vehicles(self):
         m = C.c_double(0)
         _lib.check(self.lib.tsc_mean_vehicles(self.h, C.byref(m)), "tsc_mean_vehicles")
@@ -239,11 +245,14 @@ class VecTrafficSignalNetwork:
         self.obs_kind = sig.get("observation_space", "position_matrix")
         if self.obs_kind not in ("position_matrix", "lane_features"):
             raise ValueError(f"observation_space {self.obs_kind!r}: expected position_matrix or lane_features")
-        if float(sig.get("obs_noise_std", 0.0) or 0.0) != 0.0:
-            # reference common/observations.py:72-88 draws one np.random.normal per surviving bin of the FLOAT position
-            # matrix; the batched path keeps the matrices as predicate bits on the device.  Not silently ignored:
-            raise ValueError("obs_noise_std > 0 is served by the single-env facade (pytsc_amd.TrafficSignalNetwork, "
-                             "numpy-stream parity with the reference), not by the batched VecTrafficSignalNetwork")
+        # reference common/observations.py:72-88: one np.random.normal per surviving bin of the position matrix.  The batched
+        # path draws on the device, where kr_step assembles the rows (tsc_config_t::obs_noise_std): the same law -- N(0, std)
+        # per surviving entry, clip to [0, 1], then the row's integer truncation -- from a counter-based generator instead
+        # of numpy's global stream (which R replicas cannot follow at once; the single-env facade does follow it)
+        self.obs_noise_std = float(sig.get("obs_noise_std", 0.0) or 0.0)
+        if self.obs_noise_std and self.obs_kind != "position_matrix":
+            raise ValueError("obs_noise_std applies to observation_space: position_matrix (reference "
+                             "common/observations.py:72-88,140-160)")
         self.dropout_prob = float(sig.get("obs_dropout_prob", 0.0) or 0.0)
         if self.dropout_prob and self.obs_kind != "lane_features":
             raise ValueError("obs_dropout_prob applies to observation_space: lane_features (reference "
@@ -252,6 +261,9 @@ class VecTrafficSignalNetwork:
             outputs = tuple(outputs) + ("state",)  # the lane-feature observation is assembled with the state rows
         self.tables = build_tables(self.config, n_replicas=n_replicas, set_offset=set_offset)
         self.parsed_network = self.tables.parser
+        if self.obs_noise_std:
+            self.tables.cfg.obs_noise_std = self.obs_noise_std
+            self.tables.cfg.obs_noise_seed = int(self.config.simulator["seed"]) & 0xFFFFFFFFFFFFFFFF
         self.engine = VecEngine(self.tables, device=device, want=tuple(outputs))
         self.n_replicas = n_replicas
         self.n_agents = self.tables.n_agents

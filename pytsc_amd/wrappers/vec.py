@@ -163,7 +163,8 @@ class VecDomainRandomizedEPyMARLTrafficSignalNetwork:
         out = None
         for k, e in enumerate(self.envs):
             x = getter(e)
-            out = x.clone() if out is None else torch.where(self.slot_map == k, x, out)
+            sel = (self.slot_map == k).view((-1,) + (1,) * (x.dim() - 1))
+            out = x.clone() if out is None else torch.where(sel, x, out)
         return out
 
     def is_terminated(self):

@@ -34,9 +34,9 @@ def entry(frm, to, t, vehicle=None):
             "endTime": t}
 
 
-def tables(entries, n_replicas=1):
+def tables(entries, n_replicas=1, **hip):
     cfg = Config("syn_1x1", signal={"action_space": "phase_selection", "round_robin": False},
-                 hip={"roadnet_json": net_all_green(), "flow_entries": [entries], "sim_length": 400})
+                 hip=dict({"roadnet_json": net_all_green(), "flow_entries": [entries], "sim_length": 400}, **hip))
     return build_tables(cfg, n_replicas=n_replicas)
 
 
@@ -129,3 +129,39 @@ def free_flow_positions(n_steps, v_cap=11.11, acc=2.0):
         v = v_new
         out.append(x)
     return np.array(out)
+
+
+def tie_tables(n_replicas=1, **hip):
+    """`straight_vs_straight` with the cross of two perpendicular through paths moved to 20 m on BOTH lane-links (it lies at
+    26 m / 14 m): two vehicles that start together then reach it in the same number of steps, enter their lane-links at the
+    same time and stand at the same distance from it -- the last tie-break of Cross::canPass decides
+    (tsc_flows_t::veh_priority).  The lists stay sorted by distance (the engine walks them in order); the geometry is no
+    longer that of the intersection, which the conflict logic does not care about."""
+    from pytsc_amd.roadnet import load_roadnet
+
+    cfg = Config("syn_1x1", signal={"action_space": "phase_selection", "round_robin": False},
+                 hip=dict({"roadnet_json": net_all_green(), "flow_entries": [SCENARIOS["straight_vs_straight"]],
+                           "sim_length": 400}, **hip))
+    rn = load_roadnet(cfg)
+    moved = 0
+    for k, cs in enumerate(rn.link_crosses):
+        out = []
+        for c in cs:
+            if abs(c[0] + c[3] - 40.0) < 1e-9 and abs(abs(c[0] - c[3]) - 12.0) < 1e-9:
+                c = (20.0,) + tuple(c[1:3]) + (20.0,) + tuple(c[4:])
+                moved += 1
+            out.append(tuple(c))
+        rn.link_crosses[k] = sorted(out, key=lambda t: (t[0], t[1]))
+    assert moved == 8
+    return build_tables(cfg, n_replicas=n_replicas, roadnet=rn)
+
+
+def who_braked(track):
+    """vehicle ids whose speed ever dropped while they were in the network (a vehicle that is never held back accelerates
+    monotonically up to its cap)."""
+    out = set()
+    for a, b in zip(track.rows, track.rows[1:]):
+        for v in a:
+            if v in b and b[v][2] < a[v][2] - 1e-9:
+                out.add(v)
+    return out

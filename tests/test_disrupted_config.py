@@ -119,9 +119,10 @@ def test_facade_restarts_on_the_drawn_file_and_reports_the_domain(tmp_path):
         for s in range(12):
             mask = np.asarray(env.get_action_mask())
             _, done, info = env.step([int(np.flatnonzero(m)[0]) for m in mask])
-            if s == 1:  # 10 engine steps in: nobody has finished, (almost) everybody due has entered
+            if s == 1:  # 10 engine steps in: nobody has finished; who is due has entered unless its lane's tail was in the way
                 due = int((starts < 10).sum())
-                assert due - 2 <= env.simulator.step_measurements["sim"]["n_vehicles"] <= due, (hour, cfg.flow_file)
+                n_in = env.simulator.step_measurements["sim"]["n_vehicles"]
+                assert n_in <= due and due - n_in <= max(4, 0.3 * due), (hour, cfg.flow_file, due, n_in)
             if done:
                 env.restart()
         assert env.simulator.n_starts == hour + 2  # (12 env steps = the 60-second "hour": restarted)

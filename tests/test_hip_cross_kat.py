@@ -4,7 +4,7 @@ vehicle snapshot (drivable, position, speed, id) and outputs against the oracle,
 import numpy as np
 import pytest
 
-from cross_kat_scenarios import SCENARIOS, Track, check_mutual_exclusion, tables
+from cross_kat_scenarios import SCENARIOS, Track, check_mutual_exclusion, tables, tie_tables, who_braked
 
 pytestmark = pytest.mark.gpu
 
@@ -37,4 +37,30 @@ def test_cross_scenarios_match_oracle(name, family, oracle_lib):
     assert check_mutual_exclusion(tr) is None
     c = eng.replica_counts().cpu().numpy()
     assert (c[:, 2] == len(SCENARIOS[name])).all() and eng.errors() == 0 and orc.errors() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("family", ["list", "resident"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_priority_rule_on_a_tie_matches_oracle(seed, family, oracle_lib):
+    """tsc_flows_t::veh_priority through the C-ABI: the tie scenario of tests/test_priority_rule.py under the mt19937 rule
+    (seed 0: the higher id goes first; seed 1: the lower), every vehicle of every step against the oracle."""
+    import torch
+
+    from pytsc_amd.flows import mt19937_priorities
+    from pytsc_amd.vec_env import VecEngine
+
+    kw = dict(priority_rule="mt19937", seed=seed)
+    eng = VecEngine(tie_tables(n_replicas=2, **kw), family=family)
+    orc = oracle_lib.Oracle(tie_tables(**kw))
+    tr = Track(eng.tables)
+    for s in range(40):
+        orc.step(np.zeros((1, 1), np.int32))
+        eng.step(torch.zeros((2, 1), dtype=torch.int32, device="cuda"))
+        for r in range(2):
+            assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(0), eng.snapshot(r))), (s, r)
+        tr.add(eng.snapshot(1))
+    p = mt19937_priorities(seed, 2)
+    assert who_braked(tr) == {1 if p[0] > p[1] else 0}
+    assert check_mutual_exclusion(tr) is None and eng.errors() == 0
     eng.close()

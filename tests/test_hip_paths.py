@@ -196,7 +196,7 @@ def test_async_caller_across_the_migration_threshold(oracle_lib):
         out = orc.step(acts)
         acts_all.append(acts)
         exp.append((out.obs.copy(), out.stats.copy(), out.mask.copy()))
-    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, **kw), family="auto")
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_spill_limit=-1, **kw), family="auto")  # (no spill pool: whole-handle migration)
     assert eng.family == "resident"
     acts_dev = torch.tensor(np.stack(acts_all), device="cuda")
     torch.cuda.synchronize()
@@ -238,7 +238,7 @@ def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(or
         out = orc.step(acts)
         acts_all.append(acts)
         exp.append(out.obs.copy())
-    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_margin=1, **kw), family="auto")
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_margin=1, resident_spill_limit=-1, **kw), family="auto")
     acts_dev = torch.tensor(np.stack(acts_all), device="cuda")
     torch.cuda.synchronize()
     got, fam, valid = [], [], []

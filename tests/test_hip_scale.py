@@ -282,7 +282,7 @@ def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_
 
     kw = dict(flow_rate=1500.0, n_flow_sets=2, sim_length=900, episode_limit=40)
     R = 6
-    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, **kw), family="auto")
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_spill_limit=-1, **kw), family="auto")  # (no spill pool: whole-handle migration)
     assert eng.family == "resident"
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
     rng = np.random.default_rng(21)
@@ -328,7 +328,7 @@ def test_migrated_handle_returns_to_the_resident_family_at_a_full_restart(oracle
 
     kw = dict(flow_rate=1500.0, n_flow_sets=3, sim_length=900, episode_limit=40, flow_rate_type="sequential")
     R = 4
-    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, **kw), family="auto")
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_spill_limit=-1, **kw), family="auto")  # (no spill pool: whole-handle migration)
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
     fam = lambda: eng.lib.tsc_kernel_family(eng.h)  # 1: list, 2: resident
     assert fam() == 2
