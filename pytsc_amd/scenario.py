@@ -44,8 +44,29 @@ def build_tables(config, n_replicas=None, roadnet=None, set_offset=0):
         from pytsc_amd.flows import poisson_flow_sets
 
         base = int(sim.get("flow_set_base", 0))
-        done = poisson_flow_sets(fc, float(sim.get("flow_rate", 700.0)), horizon, range(base, base + batch),
-                                 base_seed=int(sim.get("flow_seed", sim["seed"])))
+        mix = sim.get("flow_rate_mix")  # [[rate, share], ...]: demand g runs at the rate its index falls to (a heterogeneous batch)
+        if mix:
+            from pytsc_amd.flows import enumerate_walk_routes
+
+            done = enumerate_walk_routes(rn) is not None
+            bounds, acc = [], 0.0
+            for rate, share in mix:
+                acc += float(share)
+                bounds.append((acc, float(rate)))
+            if done:
+                groups = {}
+                for g in range(base, base + batch):
+                    u = ((g * 2654435761) % 4294967296) / 4294967296.0 * acc  # (a fixed pseudo-random position of demand g)
+                    rate = next(r for b, r in bounds if u < b or b == bounds[-1][0])
+                    groups.setdefault(rate, []).append(g)
+                by_g, n0 = {}, len(fc.sets)
+                for rate, gs in groups.items():  # one call per rate (the walk routes are enumerated once per call)
+                    poisson_flow_sets(fc, rate, horizon, gs, base_seed=int(sim.get("flow_seed", sim["seed"])))
+                    by_g.update(zip(gs, fc.sets[-len(gs):]))
+                fc.sets[n0:] = [by_g[g] for g in range(base, base + batch)]
+        else:
+            done = poisson_flow_sets(fc, float(sim.get("flow_rate", 700.0)), horizon, range(base, base + batch),
+                                     base_seed=int(sim.get("flow_seed", sim["seed"])))
     if not done:
         for entries in flow_entry_sets(config, rn):
             fc.add(entries, horizon)
