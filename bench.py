@@ -344,7 +344,9 @@ def roofline_valu(kinfo, R, va):
     if abs(va - r["V_a"]) > 0.10 * r["V_a"]:
         return None
     return {k: r[k] for k in ("kernel", "V_a", "valu_busy_frac", "active_lane_frac", "useful_valu_frac", "salu_per_valu",
-                              "wait_frac", "lds_bank_conflict_ratio", "waves_per_simd", "how") if k in r} | {
+                              "wait_frac", "lds_bank_conflict_ratio", "waves_per_simd", "avg_launch_us_under_pmc",
+                              "avg_launch_us_undisturbed", "valu_busy_frac_undisturbed", "useful_valu_frac_undisturbed",
+                              "valu_insts_per_launch", "how") if k in r} | {
         "source": f"profiles/{kinfo['valu_file']}",
         # hardware counters cannot be read from inside this process: a quotation of the committed separate --pmc pass,
         # tied to this run by its state only (same kernel, same replicas, V_a within 10 %)

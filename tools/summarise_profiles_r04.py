@@ -131,6 +131,15 @@ def main():
                       f"{CLOCK_GHZ} GHz); active lanes = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); waves per SIMD: one "
                       "768-thread workgroup per CU (LDS)"}
         rec["useful_valu_frac"] = rec["valu_busy_frac"] * rec["active_lane_frac"]
+        # the counter pass itself slows the launch (its HIP-event duration is what the fractions above divide by); the same
+        # instruction counts against the duration of an undisturbed run of the same command (the committed bench line):
+        und = os.path.join(P, "r04_bench_line_driver_cmd.json")
+        if os.path.exists(und):
+            u_us = json.load(open(und))["roofline"]["avg_launch_us"]
+            rec["avg_launch_us_undisturbed"] = u_us
+            rec["valu_busy_frac_undisturbed"] = allc["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * u_us * 1e3 * CLOCK_GHZ)
+            rec["useful_valu_frac_undisturbed"] = rec["valu_busy_frac_undisturbed"] * rec["active_lane_frac"]
+        rec["valu_insts_per_launch"] = allc["SQ_INSTS_VALU"]
         with open(os.path.join(P, "r04_valu_resident.json"), "w") as o:
             json.dump([rec], o, indent=1)
         print(json.dumps(rec, indent=1))
