@@ -233,28 +233,60 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
   const int ib = N.agent_inc_ptr[a], n_inc = N.agent_inc_ptr[a + 1] - ib;
   const int ob = N.agent_out_ptr[a], n_out = N.agent_out_ptr[a + 1] - ob;
   const bool staged = n_inc <= NOTIFY_LANES && n_out <= NOTIFY_LANES; // (uniform; else: the direct loads below)
+  // Round 4: every word this workgroup reads is requested before the first one is used -- the lane words of up to four
+  // staging rounds and the counts of this wavefront's lane-links (at most 64 per intersection: six rounds of twelve
+  // wavefronts) -- one round trip to memory per workgroup instead of three (a round of lane words, the next one behind its
+  // LDS stores, then the links' counts behind the barrier).
+  constexpr int NR = (2 * NOTIFY_LANES + NOTIFY_WAVES - 1) / NOTIFY_WAVES, NK = (64 + NOTIFY_WAVES - 1) / NOTIFY_WAVES;
+  const int lb = N.agent_link_ptr[a], le = N.agent_link_ptr[a + 1];
+  int va[NR], vb[NR], cl_r[NK];
   if (mine && staged) {
-    for (int j = wy; j < n_inc + n_out; j += NOTIFY_WAVES) {
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int j = wy + i * NOTIFY_WAVES;
+      va[i] = vb[i] = 0;
       if (j < n_inc) {
         const int sl = N.agent_inc_lanes[ib + j];
-        s_a[j][lx] = S.cnt[IDX(sl)];
-        s_b[j][lx] = S.ab[SIDX(N.drv_slot_base[sl])].x;
-      } else {
+        va[i] = S.cnt[IDX(sl)];
+        vb[i] = S.ab[SIDX(N.drv_slot_base[sl])].x;
+      } else if (j < n_inc + n_out) {
         const int e = N.agent_out_lanes[ob + j - n_inc];
-        s_a[NOTIFY_LANES + j - n_inc][lx] = S.cnt[IDX(e)];
-        s_b[NOTIFY_LANES + j - n_inc][lx] = S.tail_prev[IDX(e)];
+        va[i] = S.cnt[IDX(e)];
+        vb[i] = S.tail_prev[IDX(e)];
+      }
+    }
+  }
+  if (mine) {
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+      const int li = lb + wy + i * NOTIFY_WAVES;
+      cl_r[i] = li < le ? S.cnt[IDX(N.agent_links[li])] : 0;
+    }
+  }
+  if (mine && staged) {
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int j = wy + i * NOTIFY_WAVES;
+      if (j < n_inc) {
+        s_a[j][lx] = va[i];
+        s_b[j][lx] = vb[i];
+      } else if (j < n_inc + n_out) {
+        s_a[NOTIFY_LANES + j - n_inc][lx] = va[i];
+        s_b[NOTIFY_LANES + j - n_inc][lx] = vb[i];
       }
     }
   }
   __syncthreads();
   if (mine) {
     unsigned long long oe = 0, ov = 0, os = 0;
-    const int lb = N.agent_link_ptr[a], le = N.agent_link_ptr[a + 1];
-    for (int li = lb + wy; li < le; li += NOTIFY_WAVES) {
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+      const int li = lb + wy + i * NOTIFY_WAVES;
+      if (li >= le) break;
       const int link = N.agent_links[li];
       const int k = link - N.n_lanes;
       const unsigned long long bit = 1ull << (li - lb);
-      const int cl = S.cnt[IDX(link)];
+      const int cl = cl_r[i];
       int he, tpv, hs, ax;
       if (staged) {
         const int2 lo = N.link_lane_local[k]; // positions of its start / end lane among the intersection's lanes
@@ -1798,25 +1830,51 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
   const bool mine = live && r < S.R;
   const int A = N.n_agents, vis = C.visibility;
   int cur = 0, np_ = 1;
+  // Round 4: the per-lane words of the signal's incoming and outgoing lanes are REQUESTED together, before the first one
+  // is used (clamped indices, no branches: the loads of a straight-line block travel together).  The loops "load a lane's
+  // words, add them up" were some sixty dependent round trips per thread, with LDS rows limiting the CU to six wavefronts
+  // to hide them behind: ~70 us per workgroup round, 0.74 ms per env step on the 16x16 grid for a launch that moves
+  // 1.6 GB (profiles/r04_c16_kernel_stats.csv).  The sums below add the same terms in the same (lane) order.
+  constexpr int MI = TSC_MAX_CTRL_LANES;
+  int lq[MI], ln[MI], lon[MI];
+  double lsum[MI];
+  unsigned long long lbits[MI];
+  const int ib = live ? N.agent_inc_ptr[a] : 0, n_inc = live ? N.agent_inc_ptr[a + 1] - ib : 0;
+  const int ob = live ? N.agent_out_ptr[a] : 0, n_out = live ? N.agent_out_ptr[a + 1] - ob : 0;
   if (mine) {
-    int ib = N.agent_inc_ptr[a], ie = N.agent_inc_ptr[a + 1];
-    int ob = N.agent_out_ptr[a], oe = N.agent_out_ptr[a + 1];
+#pragma unroll
+    for (int k = 0; k < MI; k++) {
+      const int l = N.agent_inc_lanes[ib + (k < n_inc ? k : n_inc - 1)];
+      lq[k] = S.lane_q[IDX(l)];
+      ln[k] = S.lane_n[IDX(l)];
+      lsum[k] = S.lane_sum[IDX(l)];
+      lbits[k] = out.obs_dev ? S.lane_in_bits[IDX(l)] : 0ull;
+      lon[k] = S.lane_n[IDX(N.agent_out_lanes[ob + (k < n_out ? k : n_out - 1)])];
+    }
+  }
+  if (mine) {
     int nq = 0;
     double occ = 0, ms = 0, md = 0;
-    for (int k = ib; k < ie; k++) {
-      int l = N.agent_inc_lanes[k];
-      nq += S.lane_q[IDX(l)];
-      occ += lane_occupancy(N, S, C, r, l);
-      double m = lane_mean_speed(S, r, l);
-      ms += m;
-      md += 1 - m / N.drv_max_speed[l];
+#pragma unroll
+    for (int k = 0; k < MI; k++) {
+      if (k < n_inc) {
+        const int l = N.agent_inc_lanes[ib + k];
+        nq += lq[k];
+        occ += ln[k] / N.lane_slots[l];
+        const double m = ln[k] == 0 ? 0.0 : lsum[k] / ln[k];
+        ms += m;
+        md += 1 - m / N.drv_max_speed[l];
+      }
     }
-    occ /= (ie - ib);
-    ms /= (ie - ib);
-    md /= (ie - ib);
+    occ /= n_inc;
+    ms /= n_inc;
+    md /= n_inc;
     double oocc = 0;
-    for (int k = ob; k < oe; k++) oocc += lane_occupancy(N, S, C, r, N.agent_out_lanes[k]);
-    oocc /= (oe - ob);
+#pragma unroll
+    for (int k = 0; k < MI; k++)
+      if (k < n_out) oocc += lon[k] / N.lane_slots[N.agent_out_lanes[ob + k]];
+    for (int k = MI; k < n_out; k++) oocc += lane_occupancy(N, S, C, r, N.agent_out_lanes[ob + k]); // (more than 16 outgoing lanes)
+    oocc /= n_out;
     double pressure = fabs(occ - oocc);
     cur = S.cur_idx[IDX(a)];
     np_ = N.agent_n_phases[a];
@@ -1872,42 +1930,58 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
     }
   }
   // ---- observation rows (Q1 integer truncation, Q2 compaction)
+  // (round 4: a row's padding -- some 190 of an observation row's 324 values -- is not written value by value by the row's
+  //  thread: the wavefront clears its 64 rows with 16-byte LDS stores first; and a lane's kept bins are walked by their
+  //  bits, not by testing all `visibility` bins)
+  auto clear_rows = [&]() {
+    uint4 *z = (uint4 *)(rows_lds + (size_t)wy * 64 * row_stride); // (64 x row_stride bytes: a multiple of 256)
+    for (int i = lx; i < 4 * row_stride; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+  };
   if (out.obs_dev) {
+    clear_rows();
     if (mine) {
       unsigned char *row = rows_lds + ((size_t)wy * 64 + lx) * row_stride;
       int w = 0;
-      for (int k = N.agent_inc_ptr[a]; k < N.agent_inc_ptr[a + 1]; k++) {
-        int l = N.agent_inc_lanes[k];
+      // bit 3b of `sel`: bin b is listed (occupied and not exactly zero: value > 0)
+      unsigned long long bin0 = 0ull;
+      for (int b = 0; b < vis; b++) bin0 |= 1ull << (3 * b);
+#pragma unroll
+      for (int k = 0; k < MI; k++) {
+        if (k >= n_inc) break;
+        const int l = N.agent_inc_lanes[ib + k];
         for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
-        const unsigned long long bits = S.lane_in_bits[IDX(l)];
-        for (int b = 0; b < vis; b++) {
-          unsigned int t3 = (unsigned int)(bits >> (3 * b)) & 7u;
-          // kept iff value > 0: occupied and not exactly zero; value = trunc(clip(v, 0, 1))
-          if ((t3 & 1u) && !(t3 & 2u)) row[w++] = (t3 & 4u) ? 2 : 1;
+        const unsigned long long bits = lbits[k];
+        unsigned long long sel = bits & ~(bits >> 1) & bin0;
+        while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
+          const int b3 = __builtin_ctzll(sel);
+          sel &= sel - 1ull;
+          row[w++] = ((bits >> b3) & 4ull) ? 2 : 1;
         }
       }
-      int body = C.obs_size - TSC_MAX_PHASES;
-      for (; w < body; w++) row[w] = 0;
-      for (int i = 0; i < TSC_MAX_PHASES; i++) row[w++] = i < np_ ? (i == cur ? 2 : 1) : 0;
+      const int body = C.obs_size - TSC_MAX_PHASES;
+      for (int i = 0; i < TSC_MAX_PHASES; i++) row[body + i] = i < np_ ? (i == cur ? 2 : 1) : 0;
     }
     __syncthreads();
     if (live) agent_store_rows(rows_lds + (size_t)wy * 64 * row_stride, row_stride, out.obs_dev, C.obs_size, rb, a, A, S.R, lx);
     __syncthreads();
   }
   if (out.state_dev) {
+    clear_rows();
     if (mine) {
       unsigned char *row = rows_lds + ((size_t)wy * 64 + lx) * row_stride;
       int w = 0;
-      for (int k = N.agent_inc_ptr[a]; k < N.agent_inc_ptr[a + 1]; k++) {
-        int l = N.agent_inc_lanes[k];
+#pragma unroll
+      for (int k = 0; k < MI; k++) {
+        if (k >= n_inc) break;
+        const int l = N.agent_inc_lanes[ib + k];
         for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
-        row[w++] = (unsigned char)(S.lane_q[IDX(l)] + 1);
-        row[w++] = (unsigned char)((int)(long long)lane_occupancy(N, S, C, r, l) + 1);
-        row[w++] = (unsigned char)((int)(long long)lane_mean_speed(S, r, l) + 1);
+        row[w++] = (unsigned char)(lq[k] + 1);
+        row[w++] = (unsigned char)((int)(long long)(ln[k] / N.lane_slots[l]) + 1);
+        row[w++] = (unsigned char)((int)(long long)(ln[k] == 0 ? 0.0 : lsum[k] / ln[k]) + 1);
       }
-      int body = C.state_size - TSC_MAX_PHASES;
-      for (; w < body; w++) row[w] = 0;
-      for (int i = 0; i < TSC_MAX_PHASES; i++) row[w++] = (i < np_ && i == cur) ? 2 : 1;
+      const int body = C.state_size - TSC_MAX_PHASES;
+      for (int i = 0; i < TSC_MAX_PHASES; i++) row[body + i] = (i < np_ && i == cur) ? 2 : 1;
     }
     __syncthreads();
     if (live) agent_store_rows(rows_lds + (size_t)wy * 64 * row_stride, row_stride, out.state_dev, C.state_size, rb, a, A, S.R, lx);
