@@ -511,6 +511,9 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 // update is Jacobi (every decision reads only committed state), so vehicles can be
 // executed in any grouping.
 #define TSC_EU 2    /* slots enumerated per turn in k_enum */
+#ifndef TSC_ENUM_LB
+#define TSC_ENUM_LB 8 /* lane-links per wavefront of k_enum */
+#endif
 #define TSC_MAXQ 4  /* out-links of a lane (checked at create): one work list per out-link */
 #define TSC_NLIST (TSC_MAXQ + 1) /* work lists per lane: one per out-link + plain followers */
 // work item: (replica << 13) | (slot << 4) | out-links-empty << 3 | route-ends-here << 2 |
@@ -859,13 +862,42 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
   int rb, row;
   if (!map_block(n_rb, n_rows, rb, row)) return;
   row = __builtin_amdgcn_readfirstlane(row);
-  const bool IS_LINK = row >= N.n_lanes; // rows: the lanes, then the lane-links
-  if (IS_LINK) row -= N.n_lanes;
+  const bool IS_LINK = row >= N.n_lanes; // rows: the lanes, then the lane-links in groups of TSC_ENUM_LB
   const int lane = threadIdx.x;
   const int r = rb * 64 + lane;
   const bool own_valid = r < S.R;
-  const int d = IS_LINK ? N.n_lanes + row : row;
-  const int wl0 = IS_LINK ? N.n_lanes * TSC_NLIST + row : row * TSC_NLIST;
+  if (IS_LINK) {
+    // Round 4: a wavefront takes TSC_ENUM_LB lane-links, their counts requested together.  Three quarters of the rows
+    // of a grid are lane-links and nearly all of them are empty in all 64 replicas: one wavefront per lane-link was
+    // 590 k wavefronts per launch on the 16x16 grid that each waited for ONE round trip to memory and left.
+    const int k0 = (row - N.n_lanes) * TSC_ENUM_LB;
+    int nn[TSC_ENUM_LB];
+#pragma unroll
+    for (int u = 0; u < TSC_ENUM_LB; u++) {
+      nn[u] = 0;
+      if (own_valid && k0 + u < N.n_links) {
+        nn[u] = S.cnt[IDX(N.n_lanes + k0 + u)] & TSC_CNT_MASK;
+        S.ob[IDX(N.n_lanes + k0 + u)] = 0; // outbox of this sub-step (the executors append with atomics)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TSC_ENUM_LB; u++) {
+      const int n = nn[u];
+      if (!__builtin_amdgcn_ballot_w64(n > 0)) continue;
+      // every vehicle on a lane-link takes the full path
+      const int wl = N.n_lanes * TSC_NLIST + k0 + u;
+      int qn = 0;
+      for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl, stage[0], qn, i < n, TSC_ITEM(r, i, 0, 0, 1, i == n - 1));
+      if (qn) {
+        __syncthreads();
+        wl_flush(S, wl, stage[0], qn);
+        __syncthreads(); // (the staging area is the next lane-link's)
+      }
+    }
+    return;
+  }
+  const int d = row;
+  const int wl0 = row * TSC_NLIST;
   // the drivable's constants in one 128-byte scalar load (the record of its first list)
   const ListRec lr0 = S.wl_rec[wl0];
   const int sb = lr0.sb;
@@ -876,16 +908,6 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
     S.ob[IDX(d)] = 0; // outbox of this sub-step (the executors append with atomics)
   }
   if (!__builtin_amdgcn_ballot_w64(n > 0)) return;
-  if (IS_LINK) {
-    // every vehicle on a lane-link takes the full path
-    int qn = 0;
-    for (int i = 0; __builtin_amdgcn_ballot_w64(i < n); i++) wl_put(S, wl0, stage[0], qn, i < n, TSC_ITEM(r, i, 0, 0, 1, i == n - 1));
-    if (qn) {
-      __syncthreads();
-      wl_flush(S, wl0, stage[0], qn);
-    }
-    return;
-  }
   int olk[TSC_MAXQ];
 #pragma unroll
   for (int qq = 0; qq < TSC_MAXQ; qq++) olk[qq] = lr0.olk[qq];
@@ -1096,7 +1118,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
 #pragma unroll
         for (int q = 0; q < TSC_NLIST; q++) {
           if (q > 0 && q < TSC_MAXQ && olk[q] < 0) continue; // no such out-link (wave-uniform)
-          if (!TSC_ABL(256)) wl_put(S, wl0 + q, stage[IS_LINK ? 0 : q], qn[q], bucket == q, item);
+          if (!TSC_ABL(256)) wl_put(S, wl0 + q, stage[q], qn[q], bucket == q, item);
         }
       }
       p_dist = dist;
@@ -1658,13 +1680,14 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   int q = 0;
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
-  for (int i0 = 0; __builtin_amdgcn_ballot_w64(i0 < n); i0 += 4) {
-    double2 v[4];
+  constexpr int MU = 4; // records requested together (8: +7 % time on the 16x16 grid -- 82 VGPRs, fewer wavefronts in flight)
+  for (int i0 = 0; __builtin_amdgcn_ballot_w64(i0 < n); i0 += MU) {
+    double2 v[MU];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < MU; u++)
       if (i0 + u < n) v[u] = S.ds[DIDX(sb + i0 + u)];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < MU; u++) {
       if (i0 + u >= n) continue;
       const double dist = v[u].x, speed = v[u].y;
       if (speed < 0.1) q++;
@@ -1999,6 +2022,7 @@ __device__ double np_pairwise_sum_col(const double *a, size_t stride, int n) {
     double r0 = a[0], r1 = a[stride], r2 = a[2 * stride], r3 = a[3 * stride], r4 = a[4 * stride],
            r5 = a[5 * stride], r6 = a[6 * stride], r7 = a[7 * stride];
     int i;
+#pragma unroll 4 /* (32 loads in flight: one thread per replica walks the column alone) */
     for (i = 8; i < n - (n % 8); i += 8) {
       r0 += a[(size_t)(i + 0) * stride];
       r1 += a[(size_t)(i + 1) * stride];
@@ -2037,18 +2061,37 @@ __global__ __launch_bounds__(64 * NS_WAVES) void k_net_sums(DevNet N, DevState S
   const int nl = N.n_lanes, n_stage = (nl + NS_LANES - 1) / NS_LANES;
   int nq = 0, nveh = 0;
   double dens = 0, nms = 0, tvs = 0;
-  auto load_stage = [&](int st) {
+  // (round 4: a stage's words are REQUESTED two stages ahead and turned into terms one stage ahead: with the request and
+  //  the terms in one step a stage lasted as long as a round trip to memory -- 2.9 us x 109 stages on the 16x16 grid --
+  //  with fifteen wavefronts waiting for six loads each)
+  int rq_n[2] = {0, 0}, rq_q[2] = {0, 0};
+  double rq_s[2] = {0, 0};
+  auto request_stage = [&](int st) {
+    if (w == 0) return;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int l = st * NS_LANES + (w - 1) * 2 + j;
+      rq_n[j] = rq_q[j] = 0;
+      rq_s[j] = 0.0;
+      if (rv && l < nl) {
+        rq_n[j] = S.lane_n[IDX(l)];
+        rq_q[j] = S.lane_q[IDX(l)];
+        rq_s[j] = S.lane_sum[IDX(l)];
+      }
+    }
+  };
+  auto terms_stage = [&](int st) { // (of the words request_stage(st) left in the registers)
     if (w == 0) return;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int slot = (w - 1) * 2 + j, l = st * NS_LANES + slot;
       double occ = 0.0, nm = 0.0, mv = 0.0;
       if (rv && l < nl) {
-        const int n = S.lane_n[IDX(l)];
-        nq += S.lane_q[IDX(l)];
+        const int n = rq_n[j];
+        nq += rq_q[j];
         nveh += n;
         occ = n / (N.lane_len_pytsc[l] / C.veh_size_min_gap);
-        const double m = n == 0 ? 0.0 : S.lane_sum[IDX(l)] / n;
+        const double m = n == 0 ? 0.0 : rq_s[j] / n;
         nm = m / N.drv_max_speed[l];
         mv = m * n;
       }
@@ -2057,10 +2100,13 @@ __global__ __launch_bounds__(64 * NS_WAVES) void k_net_sums(DevNet N, DevState S
       t_mv[st & 1][slot][lx] = mv;
     }
   };
-  load_stage(0);
+  request_stage(0);
+  terms_stage(0);
+  if (n_stage > 1) request_stage(1);
   __syncthreads();
   for (int st = 0; st < n_stage; st++) {
-    if (st + 1 < n_stage) load_stage(st + 1);
+    if (st + 1 < n_stage) terms_stage(st + 1);
+    if (st + 2 < n_stage) request_stage(st + 2);
     if (w == 0) {
       const int cnt = nl - st * NS_LANES < NS_LANES ? nl - st * NS_LANES : NS_LANES;
       for (int j = 0; j < cnt; j++) { // (a lane beyond the last adds nothing: not even + 0.0)
@@ -2122,6 +2168,7 @@ __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
   double mean_speed = nveh_all == 0 ? 0.0 : tvs / (double)nveh_all;
   double pressure = np_pairwise_sum_col(S.agent_pressure + r, (size_t)S.RS, A);
   int n_changed = 0;
+#pragma unroll 16
   for (int a = 0; a < A; a++) n_changed += S.changed[IDX(a)] ? 1 : 0;
   double flick = (double)n_changed / (double)A;
   double g;
