@@ -12,7 +12,14 @@
 
 #include "../../include/pytsc_amd.h"
 
-#define TSC_CNT_MASK 0x3fffffff
+// The header word of a drivable (per replica): vehicles on it (bits 0-15), this sub-step's leavers appended to its outbox
+// (bits 16-23, k_exec's atomic adds; k_commit keeps them through its own write of the word -- the target drivables of the
+// same launch read them -- and the next k_enum clears them), TSC_NEW_BIT: its tail was inserted in this step.
+// (Round 4: the outbox count was a word of its own -- a store per drivable and replica in k_enum, a row more to read in k_commit.)
+#define TSC_CNT_MASK 0xffff
+#define TSC_OB_ONE 0x10000
+#define TSC_OB_BITS 0xff0000
+#define TSC_OB_OF(hdr) (((hdr) >> 16) & 0xff)
 #define TSC_NEW_BIT 0x40000000
 #define TSC_TAG_VID(tag) ((tag) & 0xffffff)
 #define TSC_TAG_SEQ(tag) (((uint32_t)(tag)) >> 24)
@@ -138,8 +145,8 @@ struct DevState {
   int2 *ab;     // x: aux (next drivable / link entry time), y: blocker word (TSC_BLK_*)
   int *tag;
   // per drivable [n_drv * RS]
-  int *cnt, *ob, *tail_tag, *tail_prev;
-  // outbox of this sub-step's leavers: ob = how many (appended with atomics), records [n_drv * TSC_OB_MAX * RS]
+  int *cnt, *tail_tag, *tail_prev;
+  // outbox of this sub-step's leavers: how many is in the header word cnt (TSC_OB_OF), records [n_drv * TSC_OB_MAX * RS]
   ObxRec *obx; // [drivable][TSC_OB_MAX][replica]: this sub-step's leavers
   double2 *tail;  // {dist, speed} of the tail of the committed state (the tail before a spawn)
   double2 *ntail; // next half: written by k_enum / k_exec (quiet drivables) / k_commit, then swapped in

@@ -800,7 +800,7 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         if (touch_bbv) S.nbbv[IDX(vid)] = nblk;
         if (nd > L) {
           nd -= L;
-          int ko = atomicAdd(&S.ob[IDX(d)], 1);
+          int ko = TSC_OB_OF(atomicAdd(&S.cnt[IDX(d)], TSC_OB_ONE));
           if (ko < TSC_OB_MAX) {
             size_t ox = ((size_t)d * TSC_OB_MAX + ko) * (size_t)S.RS + (size_t)r;
             ObxRec rec; // one 32-byte record: one line written here, one read by k_commit
@@ -876,8 +876,9 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
     for (int u = 0; u < TSC_ENUM_LB; u++) {
       nn[u] = 0;
       if (own_valid && k0 + u < N.n_links) {
-        nn[u] = S.cnt[IDX(N.n_lanes + k0 + u)] & TSC_CNT_MASK;
-        S.ob[IDX(N.n_lanes + k0 + u)] = 0; // outbox of this sub-step (the executors append with atomics)
+        const int hdr = S.cnt[IDX(N.n_lanes + k0 + u)];
+        nn[u] = hdr & TSC_CNT_MASK;
+        if (hdr & TSC_OB_BITS) S.cnt[IDX(N.n_lanes + k0 + u)] = hdr & ~TSC_OB_BITS; // outbox of this sub-step (the executors append with atomics)
       }
     }
 #pragma unroll
@@ -904,8 +905,9 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
   const double L = lr0.L;
   int n = 0;
   if (own_valid) {
-    n = S.cnt[IDX(d)] & TSC_CNT_MASK;
-    S.ob[IDX(d)] = 0; // outbox of this sub-step (the executors append with atomics)
+    const int hdr = S.cnt[IDX(d)];
+    n = hdr & TSC_CNT_MASK;
+    if (hdr & TSC_OB_BITS) S.cnt[IDX(d)] = hdr & ~TSC_OB_BITS; // outbox of this sub-step (the executors append with atomics)
   }
   if (!__builtin_amdgcn_ballot_w64(n > 0)) return;
   int olk[TSC_MAXQ];
@@ -1301,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     fe = N.lane_in_ptr[d + 1];
   }
   const int hdr = S.cnt[IDX(d)];
-  const int o_raw = S.ob[IDX(d)];
+  const int o_raw = TSC_OB_OF(hdr);
   const int set_r = S.set[r];
   const int t_now = S.t[r];
   int o_feed[4] = {0, 0, 0, 0};
@@ -1309,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   for (int q = 0; q < 4; q++)
     if (fb + q < fe) {
       const int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[fb + q];
-      o_feed[q] = S.ob[IDX(f)];
+      o_feed[q] = TSC_OB_OF(S.cnt[IDX(f)]);
     }
   const int n = hdr & TSC_CNT_MASK;
   const int m_self = n > 0 ? (o_raw < TSC_OB_MAX ? o_raw : TSC_OB_MAX) : 0;
@@ -1338,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         n_arr += o_feed[q] < TSC_OB_MAX ? o_feed[q] : TSC_OB_MAX;
       }
     for (int q = fb + 4; q < fe; q++) {
-      int m = S.ob[IDX(N.lane_in_links[q])];
+      int m = TSC_OB_OF(S.cnt[IDX(N.lane_in_links[q])]);
       if (m > TSC_OB_MAX) m = TSC_OB_MAX;
       if (m) {
         if (n_arr == 0) first_f = N.lane_in_links[q];
@@ -1482,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
       } else
       for (int q = fb; q < fe; q++) {
         int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[q];
-        int m = S.ob[IDX(f)];
+        int m = TSC_OB_OF(S.cnt[IDX(f)]);
         if (m > TSC_OB_MAX) m = TSC_OB_MAX;
         for (int k = 0; k < m; k++) {
           size_t ox = ((size_t)f * TSC_OB_MAX + k) * (size_t)S.RS + (size_t)r;
@@ -1545,7 +1547,8 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
     int tail_tmpl = have_tail ? tmpl_of<SINGLE>(N, vbase, TSC_TAG_VID(tl_tag)) : 0;
     spawn_if_due<SINGLE>(N, S, q_ds, r, d, sb, t_now + 1, w, have_tail, tl_dist, tail_tmpl, has_new);
   }
-  S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0);
+  // (the outbox count stays in the word: the drivables its leavers go to read it in this very launch)
+  S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0) | (hdr & TSC_OB_BITS);
 }
 
 // ----------------------------------------------------------------- k_reset
@@ -1559,7 +1562,6 @@ __global__ __launch_bounds__(256) void k_reset(DevNet N, DevState S, DevCfg C, c
   if (d >= N.n_drv || r >= S.R) return;
   if (mask && !mask[r]) return;
   // S.set / S.t were prepared by k_reset_replica (previous launch)
-  S.ob[IDX(d)] = 0;
   S.tail_prev[IDX(d)] = -1;
   int w = 0, has_new = 0;
   if (d < N.n_lanes) {
