@@ -1682,6 +1682,7 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   int q = 0;
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
+  const double inv_bin = 1.0 / bin_size;
   constexpr int MU = 4; // records requested together (8: +7 % time on the 16x16 grid -- 82 VGPRs, fewer wavefronts in flight)
   for (int i0 = 0; __builtin_amdgcn_ballot_w64(i0 < n); i0 += MU) {
     double2 v[MU];
@@ -1695,10 +1696,26 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
       if (speed < 0.1) q++;
       sum += speed;
       if (bins <= 0) continue;
-      double pos = round6(dist);
-      if (pos < 0) pos = 0;
-      else if (pos > len) pos = len;
-      int idx = (int)py_floordiv(pos, bin_size);
+      // (round 4, as the resident family's measure phase does: a vehicle clear of both windows -- by a millimetre, a
+      //  thousand times what round6 and the floor division can move it -- sets no window bit: most of a lane's length;
+      //  and floor(round(dist, 6) // bin size) as CPython computes it is the mathematical floor, which a guess from the
+      //  reciprocal IS whenever the vehicle is clear of the guessed bin's edges by 1e-5 and of the lane's end; the
+      //  divisions -- two and an fmod per vehicle, a third of this kernel's cycles were instruction issue -- are for
+      //  the others.  tests/test_measure_fastpath.py holds the host-side proof of both.)
+      if (dist > vis * bin_size + 1e-3 && dist < in0 * bin_size - 1e-3) continue;
+      int idx;
+      {
+        const double kq = floor(dist * inv_bin);
+        const double rem = fma(-kq, bin_size, dist);
+        if (kq >= 0.0 && rem > 1e-5 && rem < bin_size - 1e-5 && dist < len - 1e-5) {
+          idx = (int)kq;
+        } else {
+          double pos = round6(dist);
+          if (pos < 0) pos = 0;
+          else if (pos > len) pos = len;
+          idx = (int)py_floordiv(pos, bin_size);
+        }
+      }
       if (idx >= bins) idx = bins - 1;
       if (idx < vis) out_one |= 1u << idx;
       if (idx >= in0) {
