@@ -1990,15 +1990,16 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
       for (int b = 0; b < vis; b++) bin0 |= 1ull << (3 * b);
 #pragma unroll
       for (int k = 0; k < MI; k++) {
-        if (k >= n_inc) break;
-        const int l = N.agent_inc_lanes[ib + k];
-        for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
-        const unsigned long long bits = lbits[k];
-        unsigned long long sel = bits & ~(bits >> 1) & bin0;
-        while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
-          const int b3 = __builtin_ctzll(sel);
-          sel &= sel - 1ull;
-          row[w++] = ((bits >> b3) & 4ull) ? 2 : 1;
+        if (k < n_inc) { // (no break: the loop must unroll, lbits are registers)
+          const int l = N.agent_inc_lanes[ib + k];
+          for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
+          const unsigned long long bits = lbits[k];
+          unsigned long long sel = bits & ~(bits >> 1) & bin0;
+          while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
+            const int b3 = __builtin_ctzll(sel);
+            sel &= sel - 1ull;
+            row[w++] = ((bits >> b3) & 4ull) ? 2 : 1;
+          }
         }
       }
       const int body = C.obs_size - TSC_MAX_PHASES;
@@ -2015,12 +2016,13 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
       int w = 0;
 #pragma unroll
       for (int k = 0; k < MI; k++) {
-        if (k >= n_inc) break;
-        const int l = N.agent_inc_lanes[ib + k];
-        for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
-        row[w++] = (unsigned char)(lq[k] + 1);
-        row[w++] = (unsigned char)((int)(long long)(ln[k] / N.lane_slots[l]) + 1);
-        row[w++] = (unsigned char)((int)(long long)(ln[k] == 0 ? 0.0 : lsum[k] / ln[k]) + 1);
+        if (k < n_inc) { // (no break: the loop must unroll, lq / ln / lsum are registers)
+          const int l = N.agent_inc_lanes[ib + k];
+          for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
+          row[w++] = (unsigned char)(lq[k] + 1);
+          row[w++] = (unsigned char)((int)(long long)(ln[k] / N.lane_slots[l]) + 1);
+          row[w++] = (unsigned char)((int)(long long)(ln[k] == 0 ? 0.0 : lsum[k] / ln[k]) + 1);
+        }
       }
       const int body = C.state_size - TSC_MAX_PHASES;
       for (int i = 0; i < TSC_MAX_PHASES; i++) row[body + i] = (i < np_ && i == cur) ? 2 : 1;
