@@ -511,6 +511,9 @@ __device__ __forceinline__ void cross_scan(const DevNet &N, const DevState &S, i
 // update is Jacobi (every decision reads only committed state), so vehicles can be
 // executed in any grouping.
 #define TSC_EU 2    /* slots enumerated per turn in k_enum */
+#ifndef TSC_EXEC_OCC
+#define TSC_EXEC_OCC 4 /* wavefronts per SIMD k_exec is compiled for (5: 102 registers -- measured) */
+#endif
 #ifndef TSC_ENUM_LB
 #define TSC_ENUM_LB 8 /* lane-links per wavefront of k_enum */
 #endif
@@ -1201,7 +1204,7 @@ __global__ __launch_bounds__(PLAN_LISTS) void k_plan(DevNet N, DevState S) {
 // ------------------------------------------------------------------ k_exec
 // Persistent grid over the batch table: workgroup w takes batches w, w + G, ...
 template <bool SINGLE>
-__global__ __launch_bounds__(64, 4) void k_exec(DevNet N, DevState S, DevCfg C) {
+__global__ __launch_bounds__(64, TSC_EXEC_OCC) void k_exec(DevNet N, DevState S, DevCfg C) {
   const int lane = threadIdx.x;
   const int nb = S.wl_nb[0];
   const int2 *desc = S.wl_desc;
