@@ -101,6 +101,7 @@ struct DevNet {
   GP<double> lane_len_pytsc;
   GP<double> lane_slots; // lane_len_pytsc / veh_size_min_gap: the divisor of a lane's occupancy
   GP<int> lane_bins, lane_static;
+  GP<uint32_t> lane_static_pk; // the nine static features of a lane as 2-bit symbols (value + 1), feature j in bits 2j, 2j + 1
   GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane
   GP<int> link_start_lane, link_end_lane, link_type, link_agent, link_local;
   GP<int2> link_lane_local; // per lane-link: position of its start lane among its intersection's incoming lanes, of its end lane among the outgoing ones

@@ -1858,14 +1858,39 @@ __device__ __forceinline__ void agent_store_rows(const unsigned char *rows, int 
   }
 }
 
+// The same for observation rows held as 2-bit symbols (value + 1 in {0, 1, 2}; `ow` words per row): a float4 is one byte.
+__device__ __forceinline__ void agent_store_rows2(const unsigned int *rows, int ow, float *out, int size, int rb, int a, int A, int R,
+                                                  int lx) {
+  typedef float a_f4 __attribute__((ext_vector_type(4)));
+  const int n_rows = min(64, R - rb * 64);
+  const int q = size >> 2; // float4 per row
+  int rr = lx / q, j4 = lx - rr * q;
+  while (rr < n_rows) {
+    const unsigned int b = (rows[(size_t)rr * ow + (j4 >> 2)] >> (8 * (j4 & 3))) & 255u;
+    a_f4 v;
+    v.x = (float)((int)(b & 3u) - 1);
+    v.y = (float)((int)((b >> 2) & 3u) - 1);
+    v.z = (float)((int)((b >> 4) & 3u) - 1);
+    v.w = (float)((int)(b >> 6) - 1);
+    __builtin_nontemporal_store(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
+    j4 += 64;
+    while (j4 >= q) {
+      j4 -= q;
+      rr++;
+    }
+  }
+}
+
 // Per-agent statistics, observation / state vectors, action mask (reference
 // backends/cityflow/traffic_signal.py:101-141, common/observations.py:140-160,
 // 183-205, common/actions.py:119-131,169-188, common/traffic_signal.py:329-404).
 // Rows are assembled in LDS (one row per replica of the wave) and streamed out
 // so that the [R, A, obs] stores are contiguous 256-byte segments.
 __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S, DevCfg C, tsc_step_out_t out,
-                                                            int row_stride, int n_rb, int n_ablk) {
-  extern __shared__ unsigned char rows_lds[]; // [AGENT_WAVES][64][row_stride], values stored +1
+                                                            int row_stride, int obs_words, int n_rb, int n_ablk) {
+  // state rows: [AGENT_WAVES][64][row_stride] bytes, values stored + 1; observation rows: [AGENT_WAVES][64][obs_words]
+  // words of 2-bit symbols (obs_words > 0; 0: bytes like the state rows)
+  extern __shared__ unsigned char rows_lds[];
   int rb, ablk;
   bool live = map_block(n_rb, n_ablk, rb, ablk);
   int a = __builtin_amdgcn_readfirstlane(ablk * (int)blockDim.y + (int)threadIdx.y);
@@ -1983,7 +2008,57 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
     for (int i = lx; i < 4 * row_stride; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
   };
-  if (out.obs_dev) {
+  if (out.obs_dev && obs_words > 0) {
+    // Round 4: an observation value is -1, 0 or 1 (Q1's truncation of values clipped to [0, 1] / [-1, 1]): a row is held as
+    // 2-bit symbols, 84 bytes instead of 329 -- the rows were what limited a CU to six wavefronts of this kernel -- and a
+    // thread writes its row as a bit stream through a register (21 word stores instead of ~135 byte stores and the
+    // wavefront's clearing pass): the nine static features of a lane are one 18-bit constant (N.lane_static_pk), a kept bin
+    // two bits; 16 lanes x 2 bits = one word per column of the body, so the phase one-hot starts on a word.
+    unsigned int *rows2 = (unsigned int *)rows_lds;
+    if (mine) {
+      unsigned int *row = rows2 + ((size_t)wy * 64 + lx) * obs_words;
+      unsigned long long acc = 0ull;
+      int pos = 0, wi = 0;
+      unsigned long long bin0 = 0ull; // bit 3b of `sel`: bin b is listed (occupied and not exactly zero: value > 0)
+      for (int b = 0; b < vis; b++) bin0 |= 1ull << (3 * b);
+#pragma unroll
+      for (int k = 0; k < MI; k++) {
+        if (k < n_inc) { // (no break: the loop must unroll, lbits are registers)
+          acc |= (unsigned long long)N.lane_static_pk[N.agent_inc_lanes[ib + k]] << pos;
+          pos += 2 * TSC_LANE_STATIC;
+          if (pos >= 32) {
+            row[wi++] = (unsigned int)acc;
+            acc >>= 32;
+            pos -= 32;
+          }
+          const unsigned long long bits = lbits[k];
+          unsigned long long sel = bits & ~(bits >> 1) & bin0;
+          while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
+            const int b3 = __builtin_ctzll(sel);
+            sel &= sel - 1ull;
+            acc |= (((bits >> b3) & 4ull) ? 2ull : 1ull) << pos;
+            pos += 2;
+            if (pos >= 32) {
+              row[wi++] = (unsigned int)acc;
+              acc >>= 32;
+              pos -= 32;
+            }
+          }
+        }
+      }
+      const int body_w = (C.obs_size - TSC_MAX_PHASES) >> 4; // (16 symbols per word; the body is 16 x (9 + visibility) long)
+      if (wi < body_w) row[wi++] = (unsigned int)acc; // the last word with values; the padding (-1: symbol 0) behind it
+      while (wi < body_w) row[wi++] = 0u;
+      // phase one-hot: symbol 1 (0.0) for every phase the signal has, 2 (1.0) for the current one, 0 (-1.0) beyond
+      unsigned long long ph = (np_ >= 32 ? ~0ull : ((1ull << (2 * np_)) - 1ull)) & 0x5555555555ull;
+      ph ^= 3ull << (2 * cur);
+      row[body_w] = (unsigned int)ph;
+      row[body_w + 1] = (unsigned int)(ph >> 32);
+    }
+    __syncthreads();
+    if (live) agent_store_rows2(rows2 + (size_t)wy * 64 * obs_words, obs_words, out.obs_dev, C.obs_size, rb, a, A, S.R, lx);
+    __syncthreads();
+  } else if (out.obs_dev) {
     clear_rows();
     if (mine) {
       unsigned char *row = rows_lds + ((size_t)wy * 64 + lx) * row_stride;
