@@ -100,6 +100,10 @@ struct DevNet {
   GP<int> lane_out_ptr, lane_out_links, lane_in_ptr, lane_in_links;
   GP<double> lane_len_pytsc;
   GP<double> lane_slots; // lane_len_pytsc / veh_size_min_gap: the divisor of a lane's occupancy
+  // correctly rounded reciprocals of a lane's two divisors -- lane_slots and the speed limit -- for div_c (k_net_sums);
+  // recip_ok: every lane's divisors meet the theorem's conditions (else the kernel divides)
+  GP<double> lane_rslots, lane_rmax;
+  int recip_ok;
   GP<int> lane_bins, lane_static;
   GP<uint32_t> lane_static_pk; // the nine static features of a lane as 2-bit symbols (value + 1), feature j in bits 2j, 2j + 1
   GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane

@@ -74,6 +74,13 @@ __device__ __forceinline__ double div_c(double a, double b, double rb) {
   return fma(r, rb, q);
 }
 
+// a / b through div_c when the host found every lane's divisors fit for it (RC: a template switch of the caller, chosen by
+// DevNet::recip_ok), else the division: the same bits either way.  a: a count or a mean speed (0 or within [1e-290, 1e290]).
+template <bool RC>
+__device__ __forceinline__ double div_r(double a, double b, double rb) {
+  return RC ? div_c(a, b, rb) : a / b;
+}
+
 __device__ __forceinline__ Tm load_tm_p(const double *tbl, int id);
 __device__ __forceinline__ Tm load_tm(const DevNet &N, int id) { return load_tm_p((const double *)N.tmpl, id); }
 __device__ __forceinline__ Tm load_tm_p(const double *tbl, int id) {
@@ -2151,6 +2158,11 @@ __device__ double np_pairwise_sum_col(const double *a, size_t stride, int n) {
 // order: the same operations on the same operands in the same order per replica, the round trips overlapped.
 #define NS_WAVES 16
 #define NS_LANES 30 /* lanes per stage: two per loader wavefront */
+// (round 4: RC -- two of a term's three divisions, by the lane's slot count and by its speed limit, through div_c with the
+//  host's reciprocals: fifteen loader wavefronts on ONE CU made eight f64 divisions per stage each, and that, not memory, was
+//  what a stage lasted: 0.220 -> 0.174 ms on the 16x16 grid.  The third, speed sum / vehicle count, stays a division: its
+//  reciprocal would be a gather from a table, and with that on the chain the gain is gone -- measured.)
+template <bool RC>
 __global__ __launch_bounds__(64 * NS_WAVES) void k_net_sums(DevNet N, DevState S, DevCfg C) {
   __shared__ double t_occ[2][NS_LANES][64], t_nm[2][NS_LANES][64], t_mv[2][NS_LANES][64];
   __shared__ int t_cnt[NS_WAVES][2][64];
@@ -2189,9 +2201,9 @@ __global__ __launch_bounds__(64 * NS_WAVES) void k_net_sums(DevNet N, DevState S
         const int n = rq_n[j];
         nq += rq_q[j];
         nveh += n;
-        occ = n / (N.lane_len_pytsc[l] / C.veh_size_min_gap);
+        occ = div_r<RC>((double)n, N.lane_slots[l], N.lane_rslots[l]); // (lane_slots = lane_len_pytsc / veh_size_min_gap: the host's IEEE division)
         const double m = n == 0 ? 0.0 : rq_s[j] / n;
-        nm = m / N.drv_max_speed[l];
+        nm = div_r<RC>(m, N.drv_max_speed[l], N.lane_rmax[l]);
         mv = m * n;
       }
       t_occ[st & 1][slot][lx] = occ;

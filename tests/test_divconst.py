@@ -51,3 +51,22 @@ def test_div_c_is_the_ieee_division(lib, b):
     first = ctypes.c_double(0)
     bad = lib.divconst_mismatches(a.ctypes.data, a.size, b, ctypes.byref(first))
     assert bad == 0, (b, bad, first.value)
+
+
+def test_div_c_with_per_lane_divisors(lib):
+    """Round 4: k_net_sums divides a lane's vehicle count by its slot count (pytsc length / 7.5) and its mean speed by its
+    speed limit through div_c with reciprocals the host computes per lane (tsc_api.inc: lane_rslots, lane_rmax; a network
+    with a divisor whose significand is all ones keeps the divisions).  Checked here for the shipped lane lengths and speed
+    limits and for random divisors of their kind: counts are small integers, means are averages of speeds."""
+    rng = np.random.default_rng(2026)
+    lens = [300.0, 292.5, 280.0, 260.0, 150.0, 400.0, 800.0, 742.31, 87.3, 1000.0, 33.33]
+    divisors = [L / 7.5 for L in lens] + [11.11, 11.111, 13.89, 16.67, 8.33, 5.56, 22.22, 10000.0]
+    divisors += list(rng.uniform(0.5, 300.0, 16))
+    counts = np.arange(0, 600, dtype=np.float64)
+    for b in divisors:
+        sums = np.round(rng.uniform(0.0, 600.0, 200_000) * 1e6) / 1e6
+        n = rng.integers(1, 64, sums.size)
+        a = np.ascontiguousarray(np.concatenate([counts, rng.uniform(0.0, 40.0, 200_000), sums / n, b * counts[:64], b * (counts[:64] + 0.5)]))
+        first = ctypes.c_double(0)
+        bad = lib.divconst_mismatches(a.ctypes.data, a.size, float(b), ctypes.byref(first))
+        assert bad == 0, (b, bad, first.value)
