@@ -105,7 +105,7 @@ struct DevNet {
   GP<double> lane_rslots, lane_rmax;
   int recip_ok;
   GP<int> lane_bins, lane_static;
-  GP<uint32_t> lane_static_pk; // the nine static features of a lane as 2-bit symbols (value + 1), feature j in bits 2j, 2j + 1
+  GP<uint32_t> lane_static_pk; // the nine static features of a lane as 2-bit symbols (two's complement: -1, 0, 1), feature j in bits 2j, 2j + 1
   GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane
   GP<int> link_start_lane, link_end_lane, link_type, link_agent, link_local;
   GP<int2> link_lane_local; // per lane-link: position of its start lane among its intersection's incoming lanes, of its end lane among the outgoing ones

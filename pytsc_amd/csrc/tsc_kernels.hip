@@ -1845,10 +1845,11 @@ __device__ __forceinline__ void agent_store_rows(const unsigned char *rows, int 
     while (rr < n_rows) {
       const unsigned int w4 = *(const unsigned int *)(rows + (size_t)rr * row_stride + 4 * j4);
       a_f4 v;
-      v.x = (float)((int)(w4 & 255u) - 1);
-      v.y = (float)((int)((w4 >> 8) & 255u) - 1);
-      v.z = (float)((int)((w4 >> 16) & 255u) - 1);
-      v.w = (float)((int)(w4 >> 24) - 1);
+      // (byte k to float in one operation -- v_cvt_f32_ubyte<k> -- and the offset as a float add: two operations per value)
+      v.x = (float)(w4 & 255u) - 1.0f;
+      v.y = (float)((w4 >> 8) & 255u) - 1.0f;
+      v.z = (float)((w4 >> 16) & 255u) - 1.0f;
+      v.w = (float)(w4 >> 24) - 1.0f;
       __builtin_nontemporal_store(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
       j4 += 64;
       while (j4 >= q) {
@@ -1865,7 +1866,8 @@ __device__ __forceinline__ void agent_store_rows(const unsigned char *rows, int 
   }
 }
 
-// The same for observation rows held as 2-bit symbols (value + 1 in {0, 1, 2}; `ow` words per row): a float4 is one byte.
+// The same for observation rows held as 2-bit symbols (the value -1, 0 or 1 in two's complement: a signed bit-field extract
+// and a conversion per value; `ow` words per row): a float4 is one byte.
 __device__ __forceinline__ void agent_store_rows2(const unsigned int *rows, int ow, float *out, int size, int rb, int a, int A, int R,
                                                   int lx) {
   typedef float a_f4 __attribute__((ext_vector_type(4)));
@@ -1875,10 +1877,10 @@ __device__ __forceinline__ void agent_store_rows2(const unsigned int *rows, int 
   while (rr < n_rows) {
     const unsigned int b = (rows[(size_t)rr * ow + (j4 >> 2)] >> (8 * (j4 & 3))) & 255u;
     a_f4 v;
-    v.x = (float)((int)(b & 3u) - 1);
-    v.y = (float)((int)((b >> 2) & 3u) - 1);
-    v.z = (float)((int)((b >> 4) & 3u) - 1);
-    v.w = (float)((int)(b >> 6) - 1);
+    v.x = (float)((int)(b << 30) >> 30);
+    v.y = (float)((int)(b << 28) >> 30);
+    v.z = (float)((int)(b << 26) >> 30);
+    v.w = (float)((int)(b << 24) >> 30);
     __builtin_nontemporal_store(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
     j4 += 64;
     while (j4 >= q) {
@@ -2017,7 +2019,7 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
   };
   if (out.obs_dev && obs_words > 0) {
     // Round 4: an observation value is -1, 0 or 1 (Q1's truncation of values clipped to [0, 1] / [-1, 1]): a row is held as
-    // 2-bit symbols, 84 bytes instead of 329 -- the rows were what limited a CU to six wavefronts of this kernel -- and a
+    // 2-bit symbols (two's complement: 11, 00, 01), 84 bytes instead of 329 -- the rows were what limited a CU to six wavefronts of this kernel -- and a
     // thread writes its row as a bit stream through a register (21 word stores instead of ~135 byte stores and the
     // wavefront's clearing pass): the nine static features of a lane are one 18-bit constant (N.lane_static_pk), a kept bin
     // two bits; 16 lanes x 2 bits = one word per column of the body, so the phase one-hot starts on a word.
@@ -2043,7 +2045,7 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
           while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
             const int b3 = __builtin_ctzll(sel);
             sel &= sel - 1ull;
-            acc |= (((bits >> b3) & 4ull) ? 2ull : 1ull) << pos;
+            acc |= ((bits >> (b3 + 2)) & 1ull) << pos; // (value 1: symbol 01; value 0: 00)
             pos += 2;
             if (pos >= 32) {
               row[wi++] = (unsigned int)acc;
@@ -2054,11 +2056,10 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
         }
       }
       const int body_w = (C.obs_size - TSC_MAX_PHASES) >> 4; // (16 symbols per word; the body is 16 x (9 + visibility) long)
-      if (wi < body_w) row[wi++] = (unsigned int)acc; // the last word with values; the padding (-1: symbol 0) behind it
-      while (wi < body_w) row[wi++] = 0u;
-      // phase one-hot: symbol 1 (0.0) for every phase the signal has, 2 (1.0) for the current one, 0 (-1.0) beyond
-      unsigned long long ph = (np_ >= 32 ? ~0ull : ((1ull << (2 * np_)) - 1ull)) & 0x5555555555ull;
-      ph ^= 3ull << (2 * cur);
+      if (wi < body_w) row[wi++] = (unsigned int)(acc | (~0ull << pos)); // the last word with values; the padding (-1: 11) behind it
+      while (wi < body_w) row[wi++] = 0xFFFFFFFFu;
+      // phase one-hot: 0.0 (00) for every phase the signal has, 1.0 (01) for the current one, -1.0 (11) beyond (np_ <= 20)
+      const unsigned long long ph = (~0ull << (2 * np_)) | (1ull << (2 * cur));
       row[body_w] = (unsigned int)ph;
       row[body_w + 1] = (unsigned int)(ph >> 32);
     }
