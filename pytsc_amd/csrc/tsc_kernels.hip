@@ -1830,6 +1830,14 @@ __device__ __forceinline__ double lane_occupancy(const DevNet &N, const DevState
 }
 
 #define AGENT_WAVES 2
+// (round 4: plain stores, not non-temporal ones.  A row is 1 296 bytes: the 128-byte lines at its two ends are shared with
+//  the neighbouring signals' rows, which other wavefronts write within microseconds; through the L2 the halves merge,
+//  streamed past it they are partial-line writes: k_agent 0.42-0.46 -> 0.38 ms on the 16x16 grid, same box)
+#ifdef TSC_AGENT_NT_STORE
+#define TSC_AGENT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define TSC_AGENT_STORE(v, p) (*(p) = (v))
+#endif
 // The 64 rows of one wavefront (replicas rb * 64 ..., signal a; bytes, value + 1, in LDS) -> rows of floats of [R, A, size].
 // Round 4: every lane stores FOUR floats per instruction (16 bytes, non-temporal: written once, not read by this library) and
 // the (row, position) pairs of the 64 rows are dealt to the lanes as one index space -- 64 x 81 float4 of the observation
@@ -1850,7 +1858,7 @@ __device__ __forceinline__ void agent_store_rows(const unsigned char *rows, int 
       v.y = (float)((w4 >> 8) & 255u) - 1.0f;
       v.z = (float)((w4 >> 16) & 255u) - 1.0f;
       v.w = (float)(w4 >> 24) - 1.0f;
-      __builtin_nontemporal_store(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
+      TSC_AGENT_STORE(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
       j4 += 64;
       while (j4 >= q) {
         j4 -= q;
@@ -1881,7 +1889,7 @@ __device__ __forceinline__ void agent_store_rows2(const unsigned int *rows, int 
     v.y = (float)((int)(b << 28) >> 30);
     v.z = (float)((int)(b << 26) >> 30);
     v.w = (float)((int)(b << 24) >> 30);
-    __builtin_nontemporal_store(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
+    TSC_AGENT_STORE(v, (a_f4 *)(out + ((size_t)(rb * 64 + rr) * A + a) * size) + j4);
     j4 += 64;
     while (j4 >= q) {
       j4 -= q;
