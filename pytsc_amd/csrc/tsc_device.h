@@ -72,6 +72,16 @@ struct ObxRec {
   int tag, aux, blk, slot;
 };
 
+// What k_commit needs to keep the cross-candidate masks of the two intersections a lane touches up to date, in one
+// 64-byte scalar load: the lane's feeder lane-links (it is their end lane) and its out-links (it is their start lane) as
+// local-index masks of their intersections, and link by link (drivable index, -1: none; local index in byte q of *_loc).
+struct LaneMaskRec {
+  unsigned long long fm, om; // feeder links / out-links as bits of their intersection's local indices
+  int ag_in, ag_out;         // the intersections (-1: the lane has no such links)
+  int fid[4], oid[4];
+  unsigned int floc, oloc;
+};
+
 struct CrossRec {
   double x;   // distance of the cross on this link
   double xo;  // distance of the cross on the other link
@@ -105,6 +115,7 @@ struct DevNet {
   GP<double> lane_rslots, lane_rmax;
   int recip_ok;
   GP<int> lane_bins, lane_static;
+  GP<LaneMaskRec> lane_mask; // [n_lanes]; a lane with more than four feeder links has fid[0] = -2 (k_commit then walks the tables)
   GP<uint32_t> lane_static_pk; // the nine static features of a lane as 2-bit symbols (two's complement: -1, 0, 1), feature j in bits 2j, 2j + 1
   GP<int> lane_is_entry; // 1: some flow set spawns vehicles on this lane
   GP<int> link_start_lane, link_end_lane, link_type, link_agent, link_local;

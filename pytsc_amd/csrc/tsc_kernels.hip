@@ -217,14 +217,18 @@ static inline int grid_for(int n_rb, int n_rowblk) { return ((n_rb + 7) / 8) * 8
 // One workgroup = one intersection x 64 replicas: its waves split the intersection's
 // lane-links, each lane-link's three candidate bits are OR-ed in LDS, wave 0 writes
 // the masks (coalesced).
-__global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState S, int n_rb, int n_agents) {
+// Round 4: this kernel REBUILDS the masks -- after a reset (list_reset) -- and no longer runs once per sub-step: between two
+// sub-steps the masks change only where k_commit changed a drivable, and k_commit updates the bits there (see its end).  It
+// was a tenth of a 16x16 env step (0.25 ms x 5) for 0.2 GB of traffic.  `tick`: the per-sub-step duties it used to have
+// beside the masks (the step index, the work-list counters; diagnostic launches only: k_enum and a memset have them now).
+__global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState S, int n_rb, int n_agents, int tick) {
   __shared__ unsigned long long m_e[64], m_v[64], m_s[64];
   __shared__ int s_a[2 * NOTIFY_LANES][64], s_b[2 * NOTIFY_LANES][64]; // lane words: count, {aux of the head | previous drivable of the tail}
   int rb, a;
   const bool live = map_block(n_rb, n_agents, rb, a);
   a = __builtin_amdgcn_readfirstlane(a);
   const int lx = threadIdx.x, wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
-  if (blockIdx.x == 0) // the work-list counters of the sub-step that starts here
+  if (tick && blockIdx.x == 0) // the work-list counters of the sub-step that starts here
     for (int i = threadIdx.y * 64 + threadIdx.x; i < S.n_lists + 2; i += 64 * NOTIFY_WAVES) S.wl_nb[i] = 0;
   const int r = rb * 64 + lx;
   const bool mine = live && r < S.R;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(64 * NOTIFY_WAVES) void k_notify(DevNet N, DevState
     m_e[lx] = 0;
     m_v[lx] = 0;
     m_s[lx] = 0;
-    if (mine && a == 0) S.t[r] += 1; // the step index being executed from here on
+    if (tick && mine && a == 0) S.t[r] += 1; // the step index being executed from here on
   }
   // the words of the intersection's lanes are read ONCE per workgroup into LDS (three lane-links share a start lane, three
   // an end lane: reading them per lane-link was 180 rows of 256 bytes per workgroup, this is 84) -- this kernel is bound by
@@ -876,6 +880,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
   const int lane = threadIdx.x;
   const int r = rb * 64 + lane;
   const bool own_valid = r < S.R;
+  if (row == 0 && own_valid) S.t[r] += 1; // the step index being executed from here on (the first kernel of a sub-step)
   if (IS_LINK) {
     // Round 4: a wavefront takes TSC_ENUM_LB lane-links, their counts requested together.  Three quarters of the rows
     // of a grid are lane-links and nearly all of them are empty in all 64 replicas: one wavefront per lane-link was
@@ -1559,6 +1564,56 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   }
   // (the outbox count stays in the word: the drivables its leavers go to read it in this very launch)
   S.cnt[IDX(d)] = w | (has_new ? TSC_NEW_BIT : 0) | (hdr & TSC_OB_BITS);
+  // ---- the cross-candidate masks of the intersections (k_notify's three conditions), where this drivable's change has
+  //      changed them: a lane-link's own "vehicles on it" bit when it became empty or stopped being so; a lane's feeder
+  //      links' "the tail of my end lane came from me" bits when its tail is another vehicle than before (an arrival, a
+  //      spawn, the old tail gone); a lane's out-links' "the head of my start lane is heading for me" bits when its head is
+  //      (leavers; the first vehicle of an empty lane).  (Quiet drivables change nothing: the bit cleared with a fresh
+  //      tail's NEW flag had tail_prev -1 behind it.)
+  {
+    const int nl_ = N.n_lanes;
+    if (is_link) {
+      if ((w > 0) != (n > 0)) {
+        const int k = d - nl_;
+        unsigned long long *m = &S.arec[IDX(N.link_agent[k])].ov;
+        const unsigned long long bit = 1ull << N.link_local[k];
+        if (w > 0) atomicOr(m, bit);
+        else atomicAnd(m, ~bit);
+      }
+    } else {
+      const bool tail_changed = arrivals || has_new || (m_self > 0 && !old_tail_kept) || ((hdr & TSC_NEW_BIT) != 0);
+      const bool head_changed = m_self > 0 || (n == 0 && w > 0);
+      if (__builtin_amdgcn_ballot_w64(tail_changed || head_changed)) {
+        const LaneMaskRec lm = N.lane_mask[d]; // (one 64-byte scalar load: the lane's feeder links and out-links)
+        if (tail_changed && lm.ag_in >= 0) {
+          unsigned long long *m = &S.arec[IDX(lm.ag_in)].oe;
+          atomicAnd(m, ~lm.fm);
+          if (w > 0 && !has_new && tp >= nl_) {
+            unsigned long long bit = 0ull;
+            if (lm.fid[0] == -2) bit = 1ull << N.link_local[tp - nl_]; // (more than four feeder links)
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                if (tp == lm.fid[q]) bit = 1ull << ((lm.floc >> (8 * q)) & 63u);
+            }
+            atomicOr(m, bit);
+          }
+        }
+        if (head_changed && lm.ag_out >= 0) {
+          unsigned long long *m = &S.arec[IDX(lm.ag_out)].os;
+          atomicAnd(m, ~lm.om);
+          if (w > 0) {
+            const int ax = S.ab[SIDX(sb)].x; // (the head's next lane-link; -1: its route ends on this lane)
+            unsigned long long bit = 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (ax == lm.oid[q]) bit = 1ull << ((lm.oloc >> (8 * q)) & 63u);
+            if (bit) atomicOr(m, bit);
+          }
+        }
+      }
+    }
+  }
 }
 
 // ----------------------------------------------------------------- k_reset
