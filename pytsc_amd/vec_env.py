@@ -44,7 +44,7 @@ class VecEngine:
         self._kernel_infos = {
             "list": dict(family="list", name="k_exec", substeps_per_launch=1, traffic_file="r04_traffic_list.json", valu_file="none",
                          note="dense 64-item batches of lane / lane-link work items drawn from all replicas; "
-                              "one of ~27 launches per env step"),
+                              "one of ~22 launches per env step"),
             "resident": dict(family="resident", name="kr_step", substeps_per_launch=5,
                              traffic_file="r04_traffic_resident.json", valu_file="r04_valu_resident.json",
                              note="one workgroup per replica, state resident in LDS over the 5 sub-steps and "
