@@ -20,6 +20,9 @@
 #define TSC_OB_ONE 0x10000
 #define TSC_OB_BITS 0xff0000
 #define TSC_OB_OF(hdr) (((hdr) >> 16) & 0xff)
+// bit 24: a vehicle is on its way here in this sub-step (k_exec sets it in the TARGET's word when it appends a leaver to its
+// own drivable's outbox; k_commit's quiet test then needs no look at the feeders; its write of the word clears it)
+#define TSC_ARR_BIT 0x1000000
 #define TSC_NEW_BIT 0x40000000
 #define TSC_TAG_VID(tag) ((tag) & 0xffffff)
 #define TSC_TAG_SEQ(tag) (((uint32_t)(tag)) >> 24)

@@ -826,6 +826,10 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
             rec.slot = it;
             S.obx[ox] = rec;
           } else atomicAdd(&S.errors[1], 1);
+          // ... and tell the drivable it goes to (round 4: k_commit's "is anything arriving?" was a look at every feeder's
+          // outbox count for every drivable and replica in every sub-step: four rows per lane, one per lane-link)
+          const int tgt = IS_LINK ? el : aux;
+          if (tgt >= 0) atomicOr((unsigned int *)&S.cnt[IDX(tgt)], (unsigned int)TSC_ARR_BIT);
         }
         o_ds[DIDX(sb + it)] = make_double2(nd, v);
         if (is_tail) { // next tail record of a drivable that stays quiet (k_commit redoes it otherwise)
@@ -1321,10 +1325,13 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   const int o_raw = TSC_OB_OF(hdr);
   const int set_r = S.set[r];
   const int t_now = S.t[r];
+  // (round 4: the feeders' outbox counts are looked at only where k_exec has announced an arrival -- TSC_ARR_BIT in this
+  //  drivable's own word)
+  const bool announced = (hdr & TSC_ARR_BIT) != 0;
   int o_feed[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < 4; q++)
-    if (fb + q < fe) {
+    if (announced && fb + q < fe) {
       const int f = is_link ? N.link_start_lane[d - N.n_lanes] : N.lane_in_links[fb + q];
       o_feed[q] = TSC_OB_OF(S.cnt[IDX(f)]);
     }
@@ -1354,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
         if (n_arr == 0) first_f = N.lane_in_links[fb + q];
         n_arr += o_feed[q] < TSC_OB_MAX ? o_feed[q] : TSC_OB_MAX;
       }
-    for (int q = fb + 4; q < fe; q++) {
+    for (int q = fb + 4; announced && q < fe; q++) {
       int m = TSC_OB_OF(S.cnt[IDX(N.lane_in_links[q])]);
       if (m > TSC_OB_MAX) m = TSC_OB_MAX;
       if (m) {
