@@ -936,16 +936,15 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
   const double bd0 = brake_distance_after_accel(0.0, load_tm(N, 0), C.interval);
   // is any vehicle on a lane-link leaving this lane?  (look-ahead of a free-running head; loaded
   // with the first slots, not after them)
+  // (round 4: from the intersection's "vehicles on the lane-link" mask, which k_commit keeps up to date and which comes
+  //  with the phase in one 32-byte record -- not from the four out-links' header words: four rows less per lane)
   bool out_links_empty = true;
-  if (own_valid && n > 0) {
-#pragma unroll
-    for (int qq = 0; qq < TSC_MAXQ; qq++)
-      if (olk[qq] >= 0 && (S.cnt[IDX(olk[qq])] & TSC_CNT_MASK) > 0) out_links_empty = false;
-  }
   // which out-links are green in this replica (bit q): a head stopped at a red light is settled here
   int green_bits = 0xf;
   if (lr0.ag >= 0 && own_valid) {
-    const int raw = S.arec[IDX(lr0.ag)].raw;
+    const AgentRec ar_ = S.arec[IDX(lr0.ag)];
+    out_links_empty = (ar_.ov & N.lane_mask[d].om) == 0ull;
+    const int raw = ar_.raw;
     green_bits = 0;
 #pragma unroll
     for (int qq = 0; qq < TSC_MAXQ; qq++)
