@@ -656,14 +656,25 @@ __device__ __forceinline__ void exec_heavy(const DevNet &N, const DevState &S, c
         if (!SINGLE) e_tt = S.tail_tag[IDX(el)];
       }
       if (!IS_LINK) {
+        const LaneMaskRec lm_ = N.lane_mask[d]; // (wave-uniform: the lane's out-links with their local indices)
 #pragma unroll
         for (int qq = 0; qq < TSC_MAXQ; qq++) {
           l_cnt[qq] = 0;
           l_tt[qq] = 0;
           l_td[qq] = 0;
           l_ts[qq] = 0;
+          // (round 4: only the out-links that hold a vehicle -- the intersection's maintained mask says which, and it is
+          //  in registers already: their counts are not read at all, the empty ones' tails neither)
+          bool occ = false;
           if (lr.olk[qq] >= 0 && valid && it == 0 && !out_empty) {
-            l_cnt[qq] = S.cnt[IDX(lr.olk[qq])] & TSC_CNT_MASK;
+            unsigned int loc = 64u;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++)
+              if (lm_.oid[q2] == lr.olk[qq]) loc = (lm_.oloc >> (8 * q2)) & 63u;
+            occ = loc < 64u && ((ov >> loc) & 1ull) != 0;
+          }
+          if (occ) {
+            l_cnt[qq] = 1;
             const double2 lt_ = S.tail[IDX(lr.olk[qq])];
             l_td[qq] = lt_.x;
             l_ts[qq] = lt_.y;
