@@ -55,6 +55,8 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="
     hip = {"flow_rate": rate, "n_flow_sets": n_sets, "flow_seed": 0}
     if os.environ.get("PYTSC_AMD_RATE_MIX"):  # diagnostic: "700:0.97,1500:0.03" -- a few replicas under a heavier demand
         hip["flow_rate_mix"] = [[float(a), float(b)] for a, b in (t.split(":") for t in os.environ["PYTSC_AMD_RATE_MIX"].split(","))]
+    if os.environ.get("PYTSC_AMD_CAPACITY"):  # diagnostic: record capacity per replica of the resident family
+        hip["resident_capacity"] = int(os.environ["PYTSC_AMD_CAPACITY"])
     if os.environ.get("PYTSC_AMD_SPILL_LIMIT"):  # diagnostic: -1 = an `auto` handle without the spill pool (A/B of its cost)
         hip["resident_spill_limit"] = int(os.environ["PYTSC_AMD_SPILL_LIMIT"])
     if n_sets > MAX_SEQUENTIAL_DEMANDS:
@@ -76,16 +78,54 @@ def workload_tables(rows, cols, n_replicas, set_offset, rate, n_sets, scenario="
 
         base = cfg.simulator
         horizon = int(base["sim_length"]) + int(base["initial_wait_time"])
-        distinct = [poisson_flows(rn, rate, horizon, seed=i) for i in range(MAX_TILED_DEMANDS)]
-        hip = {"flow_entries": [distinct[(set_offset + i) % MAX_TILED_DEMANDS] for i in range(n_sets)]}
-        cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
+        distinct = _tiled_demands(rn, rate, horizon, MAX_TILED_DEMANDS)
+        cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip={})
+        # (set behind the constructor, which deep-copies its keyword arguments: 2.8 M flow entries)
+        cfg.simulator["flow_entries"] = [distinct[(set_offset + i) % MAX_TILED_DEMANDS] for i in range(n_sets)]
         tb = build_tables(cfg, n_replicas=n_replicas, roadnet=rn, set_offset=0)
         tb.distinct_demands = min(n_sets, MAX_TILED_DEMANDS)
         return tb
     cfg = Config(f"syn_{rows}x{cols}", signal={"action_space": "phase_selection", "round_robin": False}, hip=hip)
-    tb = build_tables(cfg, n_replicas=n_replicas, set_offset=set_offset)
+    rn = None
+    if rows * cols > 64 and n_sets > 2:  # (a large grid: the same demands -- poisson_flows(seed = i) -- from one process per core)
+        from pytsc_amd.roadnet import load_roadnet
+
+        rn = load_roadnet(cfg)
+        cfg.simulator["flow_entries"] = _tiled_demands(rn, rate, int(cfg.simulator["sim_length"]) + int(cfg.simulator["initial_wait_time"]), n_sets)
+    tb = build_tables(cfg, n_replicas=n_replicas, roadnet=rn, set_offset=set_offset)
     tb.distinct_demands = n_sets
     return tb
+
+
+_POOL_RN = None
+
+
+def _one_demand(a):
+    from pytsc_amd.flows import poisson_flows
+
+    rate, horizon, seed = a
+    return poisson_flows(_POOL_RN, rate, horizon, seed=seed)
+
+
+def _tiled_demands(rn, rate, horizon, n):
+    """The n distinct demands of a large grid (per-vehicle generator: 10 s each on the 16x16) -- one worker process per host
+    core when the GPU has not been touched yet in this process (a fork after that is not safe), else one after the other."""
+    global _POOL_RN
+    import multiprocessing as mp
+
+    import torch
+
+    cores = effective_cpus()[0]
+    if cores < 2 or torch.cuda.is_initialized():
+        from pytsc_amd.flows import poisson_flows
+
+        return [poisson_flows(rn, rate, horizon, seed=i) for i in range(n)]
+    _POOL_RN = rn
+    try:
+        with mp.get_context("fork").Pool(min(cores, n, 32)) as pool:
+            return pool.map(_one_demand, [(rate, horizon, i) for i in range(n)], chunksize=1)
+    finally:
+        _POOL_RN = None
 
 
 # ------------------------------------------------------------------ CPU baseline
@@ -411,11 +451,11 @@ def hour(args):
 
     from pytsc_amd.vec_env import VecEngine
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
     R = args.replicas
     n_sets = flow_sets_of(args)
-    tables = workload_tables(args.rows, args.cols, R, 0, args.rate, n_sets, args.scenario)
+    tables = workload_tables(args.rows, args.cols, R, 0, args.rate, n_sets, args.scenario)  # (before the GPU is touched: it may fork)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
     A = tables.n_agents
     eng = VecEngine(tables, device=0, want=tuple(args.outputs.split(",")), family=args.family)
     acts = torch.empty((R, A), device=dev, dtype=torch.int32)
@@ -467,16 +507,21 @@ def worker(args):
     if args.stub:
         dev, A = "cpu", 16
         eng = _StubEngine(R, A)
+        t_tab = t_create = 0.0
     else:
         from pytsc_amd.vec_env import VecEngine
 
+        n_sets = flow_sets_of(args)
+        t_tab = time.perf_counter()
+        tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, n_sets, args.scenario)  # (before the GPU is touched: it may fork)
+        t_tab = time.perf_counter() - t_tab
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
-        n_sets = flow_sets_of(args)
-        tables = workload_tables(args.rows, args.cols, R, rank * R, args.rate, n_sets, args.scenario)
         tables.cfg.replica_base = rank * R  # the policy's draws follow the GLOBAL replica index, like the flow sets
         A = tables.n_agents
+        t_create = time.perf_counter()
         eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")), family=args.family)
+        t_create = time.perf_counter() - t_create
     red_dev = dev if (world_size > 1 and not args.stub and not args.one_gpu_rehearsal) else "cpu"
     torch.manual_seed(0)
     buf = eng.observe()
@@ -587,6 +632,9 @@ def worker(args):
             hour_state = run_hour(eng, R, A, acts, args.family)
             errors = max(errors, hour_state["device_errors"])
             stalled = hour_state["stalled_replicas"]
+    # start-up of the slowest rank (every rank generates its own demands and uploads its own tables)
+    t_tab = sharding.max_over_ranks(t_tab, device=red_dev)
+    t_create = sharding.max_over_ranks(t_create, device=red_dev)
     total_units = sharding.sum_over_ranks(R * A * args.steps, device=red_dev)
     v_mean = sharding.sum_over_ranks(0.5 * (v0 + v1), device=red_dev) / world_size
     value = total_units / elapsed
@@ -643,6 +691,7 @@ def worker(args):
                 "stalled_replicas": stalled, "kernel_family": kinfo.get("family"),
                 "flow_sets_per_gpu": None if args.stub else n_sets,
                 "distinct_demands_per_gpu": None if args.stub else getattr(tables, "distinct_demands", n_sets),
+                "startup_s": {"table_build_max_over_ranks": round(t_tab, 2), "tsc_create_max_over_ranks": round(t_create, 2)},
             },
             "roofline": {
                 # the bound the contract names for this tier; the path is NOT bandwidth-bound (the step would take ~50 us

@@ -325,6 +325,8 @@ def enumerate_walk_routes(rn, turn_probs=(0.1, 0.3, 0.6), max_len=None, limit=20
     renormalised).  {road: ([route tuples], probabilities)}; None when there are more than `limit` routes (large grids:
     the number grows exponentially with the diameter)."""
     inc, out = fringe_roads(rn)
+    if len(inc) > 32:  # (larger than an 8x8 grid: hopeless, and finding that out route by route takes 15 s on the 16x16)
+        return None
     conn, out_set = _road_turns(rn), set(out)
     if max_len is None:
         max_len = _graph_diameter(rn) + 2
@@ -334,6 +336,8 @@ def enumerate_walk_routes(rn, turn_probs=(0.1, 0.3, 0.6), max_len=None, limit=20
         routes, probs = [], []
         stack = [((start,), 1.0)]
         while stack:
+            if total + len(routes) > limit or len(stack) > limit:  # (checked as the walk goes: a 16x16 grid has ~1e12 routes per road)
+                return None
             route, p = stack.pop()
             cands = [(conn.get(route[-1], {}).get(t), turn_probs[i]) for i, t in enumerate(turns)]
             cands = [(n, w) for n, w in cands if n is not None and n not in route]

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--preroll", type=int, default=150)
     ap.add_argument("--replicas", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=8, help="env steps traced (workgroup 0 = replica 0 each time)")
+    ap.add_argument("--rate", type=float, default=700.0, help="veh/h per entry road (150: a near-empty network -- the floor of a step)")
+    ap.add_argument("--sets", type=int, default=8)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -32,7 +34,7 @@ def main():
     from pytsc_amd.vec_env import VecEngine
 
     R = args.replicas
-    tables = bench.workload_tables(4, 4, R, 0, 700.0, 8)
+    tables = bench.workload_tables(4, 4, R, 0, args.rate, args.sets)
     eng = VecEngine(tables, device=0, want=tuple(bench.DEFAULT_OUTPUTS.split(",")), family="resident")
     acts = torch.empty((R, tables.n_agents), device="cuda:0", dtype=torch.int32)
     buf = eng.observe()
