@@ -178,6 +178,7 @@ class RoadNet:
         self.agent_ids = [it["id"] for it in self.intersections if not it["virtual"]]
         self.agent_index = {a: k for k, a in enumerate(self.agent_ids)}
         self.links = []  # dicts
+        self.inconsistent = []  # road links that name undefined roads / lanes (see below)
         self.lane_out_links = [[] for _ in self.lane_ids]
         self.lane_in_links = [[] for _ in self.lane_ids]
         self.agent_links = [[] for _ in self.agent_ids]
@@ -194,8 +195,16 @@ class RoadNet:
                     if rl_idx in ph["availableRoadLinks"]:
                         mask |= 1 << p
                 for ll in rl["laneLinks"]:
-                    s = self.lane_index[f"{rl['startRoad']}_{ll['startLaneIndex']}"]
-                    e = self.lane_index[f"{rl['endRoad']}_{ll['endLaneIndex']}"]
+                    s = self.lane_index.get(f"{rl['startRoad']}_{ll['startLaneIndex']}")
+                    e = self.lane_index.get(f"{rl['endRoad']}_{ll['endLaneIndex']}")
+                    if s is None or e is None:
+                        # a road link that names a road / lane the file does not define (the reference ships one such file,
+                        # syn_1x7): the PARSER works on names, as the reference's does, and accepts it; the engine tables
+                        # cannot be built from it -- pytsc_amd.tables.Tables refuses with this list (TSC_EINVAL's message)
+                        self.inconsistent.append(f"intersection {it['id']}: road link {rl_idx} ({rl['startRoad']} -> {rl['endRoad']}) "
+                                                 f"names lane {rl['startRoad'] if s is None else rl['endRoad']}_"
+                                                 f"{ll['startLaneIndex'] if s is None else ll['endLaneIndex']}, which no road defines")
+                        continue
                     pts = [(float(p["x"]), float(p["y"])) for p in ll["points"]]
                     k = len(self.links)
                     self.links.append(

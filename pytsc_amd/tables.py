@@ -103,6 +103,10 @@ class Tables:
 
     def __init__(self, parser, flow_compiler, config, n_replicas, set_offset=0):
         rn = parser.rn
+        if getattr(rn, "inconsistent", None):
+            # (the C-ABI would answer TSC_EINVAL; said here, with the reason, before any table is built)
+            raise ValueError("inconsistent road network (TSC_EINVAL): " + "; ".join(rn.inconsistent[:3]) +
+                             (f" ... {len(rn.inconsistent)} road links in all" if len(rn.inconsistent) > 3 else ""))
         self.rn = rn
         self.parser = parser
         self.fc = flow_compiler

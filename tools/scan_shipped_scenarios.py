@@ -54,7 +54,7 @@ def main():
                 if "intersections" not in net:  # a flow file that carries "roadnet" in its name
                     continue
                 res[key], _ = check(net)
-            except KeyError as e:  # a road link names a road / lane the file does not define
+            except (KeyError, ValueError) as e:  # a road link names a road / lane the file does not define
                 res[key] = dict(rc=None, note=f"inconsistent file: {type(e).__name__}: {e}"[:200])
             print(key, res[key], flush=True)
             if d in SHIP and os.path.basename(path) == SHIP[d] and res[key].get("rc") == 0:
