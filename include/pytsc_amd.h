@@ -39,8 +39,8 @@
  * the step in flight -- are updated in the order of that stream: a caller that
  * changes stream synchronises the old one first).
  *
- * The same table structs are consumed by the CPU oracle (oracle/tsc_oracle.h),
- * which is test infrastructure only.
+ * The same table structs are consumed by the CPU oracle (oracle/tsc_oracle.c includes
+ * this header; oracle/pyoracle.py binds it), which is test infrastructure only.
  */
 #ifndef PYTSC_AMD_H
 #define PYTSC_AMD_H
@@ -92,7 +92,9 @@ extern "C" {
 
 /* Kernel families (same results, bit for bit):
  *   LIST      state in HBM, replica-fastest arrays, one wavefront = 64 replicas of one drivable,
- *             dense work lists across replicas, ~27 launches per env step; any network size.
+ *             dense work lists across replicas, 26 kernel launches + 5 counter memsets per env step (k_phase;
+ *             5 x {k_enum, k_plan, k_exec, k_commit}; k_measure, k_agent, k_net_sums, k_local_rewards,
+ *             k_stats); any network size.
  *   RESIDENT  one workgroup per replica, the replica's whole state in LDS across the delta_time
  *             sub-steps and the measurement, ONE launch per env step; networks whose replica fits
  *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the

@@ -54,10 +54,8 @@ def load():
     lib.tsc_reset.argtypes = [vp, vp, vp]
     lib.tsc_reset_sets.argtypes = [vp, vp, vp, vp]
     lib.tsc_replica_counts.argtypes = [vp, vp, vp]
-    if hasattr(lib, "tsc_park"):  # (older builds of the library in a same-box A/B, tools/ab_bench.py, lack the newest entry points)
-        lib.tsc_park.argtypes = [vp, vp, vp]
-    if hasattr(lib, "tsc_spill_counts"):
-        lib.tsc_spill_counts.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.tsc_park.argtypes = [vp, vp, vp]
+    lib.tsc_spill_counts.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.tsc_step.argtypes = [vp, vp, C.POINTER(TscStepOut), vp]
     lib.tsc_observe.argtypes = [vp, C.POINTER(TscStepOut), vp]
     lib.tsc_lane_detail.argtypes = [vp, vp, vp, vp, C.c_int32, vp]

@@ -63,6 +63,62 @@ def test_4x4_r4096_linked_to_oracle(family, oracle_lib):
     _run_linked(oracle_lib, "syn_4x4", 4096, 100, snap_at=(50, 100), min_veh=700, family=family)
 
 
+@pytest.mark.parametrize("family,base", [("resident", 0), ("resident", 4096), ("list", 0), ("list", 4096)])
+def test_4x4_r4096_batch_demands_linked_to_oracle(family, base, oracle_lib):
+    """The driver-run workload's OWN inputs (VERDICT r4 "what's weak" 2): the tables built exactly as bench.py builds
+    them -- `bench.workload_tables`: 4096 demands from the array generator `poisson_flow_sets`, one per replica, demand
+    g = base + replica (base 4096 = rank 1's shard of a multi-GPU job) -- on both kernel families; replicas {0, 1, 63, 64,
+    65, R/2, R-1} against oracle runs of exactly those demands and the actions the device drew, 100 env steps: every
+    output of every step, every vehicle at steps 50 and 100, K5 for all replicas."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from pytsc_amd.vec_env import VecEngine
+
+    R = 4096
+    sel = [0, 1, 63, 64, 65, R // 2, R - 1]
+    tb = bench.workload_tables(4, 4, R, base, 700.0, R)
+    assert tb.distinct_demands == R and tb.flows.n_sets == R
+    tb.cfg.replica_base = base  # (what bench.worker sets: the policy's draws follow the global replica index)
+    eng = VecEngine(tb, family=family)
+    # the oracle's tables: the same demands base + 0 ... base + R - 1 generated again (set s <-> demand base + s),
+    # seven replicas, each told its set
+    to = bench.workload_tables(4, 4, len(sel), base, 700.0, R)
+    for s_ in sel:  # the two builds hold the same demands
+        assert np.array_equal(tb.fc.sets[s_].veh_start, to.fc.sets[s_].veh_start)
+    orc = oracle_lib.Oracle(to)
+    orc.reset(sets=np.asarray(sel, np.int32))
+    sel_t = torch.tensor(sel, device="cuda")
+    buf, out = eng.observe(), orc.observe()
+    assert np.array_equal(buf["mask"][sel_t].cpu().numpy(), out.mask)
+    names = ("obs", "mask", "stats", "local_reward64", "global_reward64", "agent_stats", "phase", "state", "done", "terminated")
+    for s in range(100):
+        acts = eng.random_valid_actions(buf["mask"], seed=1234)
+        buf = eng.step(acts)
+        out = orc.step(acts[sel_t].cpu().numpy())
+        for k in names:
+            got = buf[k][sel_t].cpu().numpy()
+            assert np.array_equal(got, getattr(out, k)), (k, s, np.argwhere(got != getattr(out, k))[:4])
+        if (s + 1) in (50, 100):
+            for i, r in enumerate(sel):
+                a, b = orc.snapshot(i), eng.snapshot(r)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (s, r)
+    c = eng.replica_counts().cpu().numpy()
+    assert np.array_equal(c[:, 0], c[:, 1] + c[:, 2])  # K5, every replica
+    assert c[:, 0].min() > 0 and c[:, 2].max() > 0
+    # the demands really are distinct: vehicles entered differ between neighbouring replicas
+    assert len(np.unique(c[:64, 0])) > 8
+    assert eng.mean_vehicles() > 700
+    assert eng.errors() == 0 and orc.errors() == 0
+    assert eng.family == family
+    eng.close()
+    orc.close()
+
+
 @pytest.mark.parametrize("family", ["list", "resident"])
 def test_4x4_r8192_linked_to_oracle(family, oracle_lib):
     """The per-GPU shard of BASELINE config 3 (65536 replicas over 8 GPUs = 8192 each)."""
