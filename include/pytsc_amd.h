@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define TSC_ABI_VERSION 4
+#define TSC_ABI_VERSION 5
 
 /* error codes */
 #define TSC_OK 0
@@ -207,6 +207,17 @@ typedef struct tsc_net {
 
   /* vehicle templates [n_tmpl*TSC_TMPL_STRIDE] */
   const double *tmpl;
+
+  /* ABI 5 -- the movements of every phase, for the per-phase scores of the rule-based controllers
+   * (tsc_step_out_t::phase_scores_dev; reference controllers/controllers.py:93-112,153-178,227-242 walk
+   * config["phase_to_inc_out_lanes"][phase]): [n_agents * TSC_MAX_AGENT_PHASES * 4] words, per (agent, PyTSC phase index):
+   *   word 0      bit k set: the agent's k-th incoming lane (agent_inc_lanes order) is a key of the phase's dict
+   *   words 1, 2  sixteen 4-bit fields: field k = index, among the agent's outgoing lanes (agent_out_lanes order), of the
+   *               LAST outgoing lane listed for incoming lane k (MaxPressureController counts only that one: :166-176)
+   *   word 3      0
+   * NULL: the host did not provide it (an agent with more than 16 incoming or outgoing lanes): phase_scores_dev and
+   * tsc_controller_actions then return TSC_EUNSUP. */
+  const uint32_t *agent_phase_moves;
 } tsc_net_t;
 
 /*
@@ -280,7 +291,10 @@ typedef struct tsc_config {
    * vanish as without noise (Q2) and take no draw.  The draws are a counter-based generator keyed on (seed, replica, engine
    * step, signal, lane, ordinal of the surviving bin): reproducible, independent across replicas -- the law of the
    * reference's noise, not numpy's stream (the single-env facade follows that one).  0 = off: rows bit for bit those of a
-   * handle without the fields.  Resident family only (TSC_EUNSUP on the list family). */
+   * handle without the fields.  Both kernel families (ABI 5; the resident family draws where kr_step assembles the rows, the
+   * list family in k_agent from per-bin values k_measure keeps: the same key gives the same draw on either).  A handle
+   * with noise runs the full-size class of the resident family only and has no stand-by (no migration, no spill pool):
+   * a replica that runs out of vehicle records there stalls with an error (tsc_errors). */
   double obs_noise_std;
   uint64_t obs_noise_seed;
 } tsc_config_t;
@@ -304,6 +318,14 @@ typedef struct tsc_step_out {
                               * 0: the replica is STALLED (resident family, out of vehicle records: see TSC_FAMILY_AUTO
                               * above) -- its rows in the other buffers were not written by this call and still hold its
                               * last completed step.  Always 1 on the list family. */
+  int16_t *phase_scores_dev; /* ABI 5 -- [R, A, TSC_MAX_PHASES, 3]: what the reference's rule-based controllers compute per
+                              * phase from the position matrices (controllers/controllers.py): [0] stopped vehicles in the
+                              * incoming windows of the phase's lanes (bins == 0.0; GreedyController :93-112), [1] vehicles
+                              * in those windows (bins >= 0; SOTLController :227-242), [2] sum over the phase's incoming lanes
+                              * of |vehicles in its window - vehicles in the outgoing window of its LAST outgoing lane|
+                              * (MaxPressureController :153-178).  Phases beyond the signal's own: 0.  Written where the
+                              * step assembles the observation rows (the window bits are on chip there): no second pass
+                              * over the state, no [R, A, P, lanes] tensor on the caller's side. */
 } tsc_step_out_t;
 
 typedef struct tsc_env *tsc_handle_t;
@@ -332,7 +354,10 @@ int tsc_reset_sets(tsc_handle_t h, const uint8_t *reset_mask_dev,
  * valid_dev[r] = 0) until a tsc_reset / tsc_reset_sets that selects them starts them again from an empty network.  What
  * a batched multi-map environment needs (reference wrappers/epymarl.py:112-336 draws one of several maps at every
  * simulated-hour restart: with one handle per map, a slot's replicas in the maps it is not playing are parked and cost
- * a workgroup launch each).  Resident family only (TSC_EUNSUP on the list family, which steps every replica). */
+ * a workgroup launch each).  Both kernel families (ABI 5).  On the resident family a parked replica keeps its state as it
+ * is; on the list family its vehicle-level state is NOT kept consistent while it is parked (tsc_snapshot / tsc_lane_detail of
+ * it are unspecified until the reset that starts it again) -- its rows are not written and valid_dev says so, which is all a
+ * caller may rely on. */
 int tsc_park(tsc_handle_t h, const uint8_t *park_mask_dev, void *stream);
 
 /* One env step for all replicas: apply actions_dev[R, A], advance delta_time
@@ -344,6 +369,27 @@ int tsc_step(tsc_handle_t h, const int32_t *actions_dev,
 
 /* Measure + fill outputs without stepping (state right after create/reset). */
 int tsc_observe(tsc_handle_t h, const tsc_step_out_t *out, void *stream);
+
+/* The reference's rule-based controllers (pytsc/controllers/controllers.py:26-268) for every replica and signal in ONE
+ * launch, from the outputs of the step just made: phase_dev [R, A, 3] and phase_scores_dev [R, A, TSC_MAX_PHASES, 3] as
+ * tsc_step wrote them.  actions_dev [R, A] int32 = the action to hand to the next tsc_step (a target phase index on the
+ * phase_selection action space -- what controllers/evaluate.py:26,57-58 forces --, switch / stay on phase_switch).
+ *   TSC_CTRL_FIXED_TIME   p0 = green time (25): stay while green and time_on_phase < p0, else the next phase (:39-54)
+ *   TSC_CTRL_GREEDY       on a green phase the allowable phase with the most stopped vehicles, else the next (:69-112)
+ *   TSC_CTRL_MAX_PRESSURE ... with the largest pressure (:127-178)
+ *   TSC_CTRL_SOTL         p0 = theta (3), p1 = mu (4), p2 = phi_min (5) (:200-242)
+ *   TSC_CTRL_RANDOM       uniform among the allowable phases (:245-268)
+ * Allowable phases: TLSFreePhaseSelectLogic / TLSRoundRobinPhaseSelectLogic (common/traffic_signal.py:329-404) from
+ * (phase, time on it).  Ties (the reference: np.random.choice among the maximisers) and the random rule draw from a
+ * counter-based generator keyed on (seed, replica_base + replica, signal, calls so far): the same law, not numpy's
+ * stream. */
+#define TSC_CTRL_FIXED_TIME 0
+#define TSC_CTRL_GREEDY 1
+#define TSC_CTRL_MAX_PRESSURE 2
+#define TSC_CTRL_SOTL 3
+#define TSC_CTRL_RANDOM 4
+int tsc_controller_actions(tsc_handle_t h, int32_t kind, int32_t p0, int32_t p1, int32_t p2, uint64_t seed,
+                           const int32_t *phase_dev, const int16_t *phase_scores_dev, int32_t *actions_dev, void *stream);
 
 /* Per-lane measurements of the last measure pass:
  *  lane_counts_dev [R, n_lanes, 2] (n_vehicles, n_queued) int32
@@ -389,7 +435,9 @@ int tsc_errors(tsc_handle_t h, int32_t *n_errors);
  *  [2] (vehicle, sub-step)s that scanned their crosses serially because the on-chip task list was full
  *  [3] of [0]: not forced -- two hand-offs really touched the same list end in one sub-step
  *  [4] of [1]: not forced -- a vehicle really left its list from behind another one
- *  [5] replicas that ran out of records and stalled until the handle migrated */
+ *  [5] replicas that ran out of records and stalled until the handle migrated
+ *  [6] two-class handles: (replica, step)s the small class abandoned within the step and the full-size launch redid
+ *  [7] two-class handles: class changes decided at the end of a step (either direction) */
 #define TSC_N_PATHS 8
 int tsc_path_counts(tsc_handle_t h, int64_t *counts);
 
@@ -397,6 +445,12 @@ int tsc_path_counts(tsc_handle_t h, int64_t *counts);
  * counts[4] int32 = (replicas living in the pool now, pool slots handed out since the last full restart, record capacity
  * of a pool slot, resident_spill_limit in force); all 0 for a handle without a pool. */
 int tsc_spill_counts(tsc_handle_t h, int32_t *counts);
+
+/* The classes of a two-class handle (resident family, ABI 5): replicas whose state needs few vehicle records are stepped by
+ * 512-thread workgroups with an LDS image of at most 80 KB -- two of them share a CU, 1.5-1.7x the rate per replica --, the
+ * others by the full-size workgroups; a replica changes class by a word of its blob's header, set by the kernel itself.
+ * counts[2] int32 = (replicas in the small class, in the full-size class) now (synchronous); (0, R) without a small class. */
+int tsc_class_counts(tsc_handle_t h, int32_t *counts);
 
 /* Mean number of running vehicles per replica at the last measure pass
  * (synchronous; used for reporting V_a). */

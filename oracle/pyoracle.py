@@ -75,11 +75,13 @@ class StepBuffers:
         self.phase = np.zeros((R, A, 3), np.int32)
         self.local_reward64 = np.zeros((R, A), np.float64)
         self.global_reward64 = np.zeros((R,), np.float64)
+        self.phase_scores = np.zeros((R, A, 20, 3), np.int16)  # [R, A, TSC_MAX_PHASES, 3]
         p = lambda a: a.ctypes.data
         self.struct = TscStepOut(
             p(self.obs), p(self.state), p(self.mask), p(self.local_reward), p(self.global_reward),
             p(self.done), p(self.terminated), p(self.stats), p(self.agent_stats), p(self.phase),
-            p(self.local_reward64), p(self.global_reward64),
+            p(self.local_reward64), p(self.global_reward64), None,
+            p(self.phase_scores) if getattr(tables, "phase_moves", None) is not None else None,
         )
 
 

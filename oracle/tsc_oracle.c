@@ -961,6 +961,41 @@ static void fill_outputs(orc_t *o, int ri, const tsc_step_out_t *out) {
       p[1] = r->time_on_phase[a];
       p[2] = r->phase_changed[a];
     }
+    /* What the reference's rule-based controllers compute per phase from the position matrices
+     * (pytsc/controllers/controllers.py): GreedyController._compute_queue_for_phase :93-112 -- bins == 0.0 of
+     * pos_mat[-visibility:] over the phase's incoming lanes; SOTLController._compute_flow_for_phase :227-242 -- bins >= 0.0
+     * of the same windows; MaxPressureController._compute_pressure_for_phase :153-178 -- sum over the incoming lanes of
+     * |vehicles in its window - vehicles in pos_mat[:visibility] of the LAST outgoing lane listed for it| (the loop over
+     * out_lanes overwrites, :171-176).  The movements come from tsc_net_t::agent_phase_moves. */
+    if (out->phase_scores_dev && n->agent_phase_moves) {
+      int np_s = n->agent_n_phases[a];
+      for (int p_ = 0; p_ < TSC_MAX_PHASES; p_++) {
+        int sq = 0, sf = 0, sp = 0;
+        if (p_ < np_s) {
+          const uint32_t *mv = n->agent_phase_moves + ((size_t)a * TSC_MAX_AGENT_PHASES + p_) * 4;
+          unsigned long long sel = (unsigned long long)mv[1] | ((unsigned long long)mv[2] << 32);
+          for (int k = 0; k < ie - ib && k < 16; k++) {
+            if (!((mv[0] >> k) & 1u)) continue;
+            int l = n->agent_inc_lanes[ib + k];
+            int lo = n->agent_out_lanes[ob + (int)((sel >> (4 * k)) & 15ull)];
+            int plen = posmat_len(o, r, l), n_in = 0, n_z = 0, n_o = 0;
+            for (int b = plen - vis; b < plen; b++) {
+              double v = posmat_at(o, r, l, b);
+              n_z += v == 0.0;
+              n_in += v >= 0.0;
+            }
+            for (int b = 0; b < vis; b++) n_o += posmat_at(o, r, lo, b) >= 0.0;
+            sq += n_z;
+            sf += n_in;
+            sp += abs(n_in - n_o);
+          }
+        }
+        int16_t *ps = out->phase_scores_dev + (((size_t)ri * A + a) * TSC_MAX_PHASES + p_) * 3;
+        ps[0] = (int16_t)sq;
+        ps[1] = (int16_t)sf;
+        ps[2] = (int16_t)sp;
+      }
+    }
     /* PositionMatrix.get_observations (common/observations.py:140-160) with
      * the pad_list integer truncation (utils.py:91-112) and the >0 compaction
      * (observations.py:72-88) */

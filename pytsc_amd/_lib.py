@@ -18,7 +18,7 @@ SYMBOLS = (
     "tsc_abi_version", "tsc_create", "tsc_destroy", "tsc_reset", "tsc_step", "tsc_observe",
     "tsc_lane_detail", "tsc_snapshot", "tsc_errors", "tsc_mean_vehicles", "tsc_obs_size",
     "tsc_state_size", "tsc_n_actions", "tsc_profile_enable", "tsc_profile_read",
-    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_kernel_variant", "tsc_check_tables", "tsc_path_counts", "tsc_park", "tsc_spill_counts",
+    "tsc_lane_window_counts", "tsc_random_valid_actions", "tsc_reset_sets", "tsc_replica_counts", "tsc_kernel_family", "tsc_kernel_variant", "tsc_check_tables", "tsc_path_counts", "tsc_park", "tsc_spill_counts", "tsc_controller_actions", "tsc_class_counts",
 )
 
 ERRORS = {-1: "TSC_EINVAL (bad argument / inconsistent tables)",
@@ -71,7 +71,9 @@ def load():
         getattr(lib, f).argtypes = [vp]
     lib.tsc_check_tables.argtypes = [C.POINTER(TscNet), C.POINTER(TscFlows), C.POINTER(TscConfig),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    if lib.tsc_abi_version() != 4:
+    lib.tsc_class_counts.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.tsc_controller_actions.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp, vp, vp, vp]
+    if lib.tsc_abi_version() != 5:
         raise RuntimeError("libpytsc_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -38,6 +38,18 @@ def check_no_vector_spills(report, kernel="kr_step"):
                 bad.append((name, line.split("remark:")[-1].strip()))
     if bad:
         raise RuntimeError("vector register spills in the resident kernel: %r" % bad)
+    # the small class (512 threads) is worth building only when TWO of its workgroups fit a CU: 16 wavefronts = 4 per SIMD
+    # = at most 128 vector registers each (1.5-1.7x; with more the hardware silently runs one workgroup per CU)
+    fat, name = [], None
+    for line in report.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif name and kernel in name and "ILi" in name and "Li512E" in name and " VGPRs:" in line and "Spill" not in line:
+            n = int(line.split("VGPRs:")[1].split()[0])
+            if n > 128:
+                fat.append((name, n))
+    if fat and not os.environ.get("PYTSC_AMD_BUILD_ANY_VGPRS"):
+        raise RuntimeError("512-thread instantiations of the resident kernel need <= 128 vector registers: %r" % fat)
 
 
 def build(force=False, verbose=False, extra=(), out=None, report=False):

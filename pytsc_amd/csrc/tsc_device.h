@@ -142,8 +142,30 @@ struct DevNet {
   GP<int> set_veh_ptr, veh_route, veh_start, veh_tmpl, spawn_ptr, spawn_vid, created_cnt;
   GP<long long> created_tsum;
   GP<int> veh_prio; // tsc_flows_t::veh_priority (null: the lower vehicle id goes first)
+  GP<uint4> agent_moves; // tsc_net_t::agent_phase_moves ([n_agents * TSC_MAX_AGENT_PHASES]; null: not provided)
 };
 
+// counter-based normal draws of the device-side observation noise (tsc_config_t::obs_noise_std): murmur3 finaliser +
+// Box-Muller, keyed on (seed, global replica, engine step) -> key0, then (signal, lane, ordinal of the surviving bin) -- the
+// same key gives the same draw on either kernel family
+__device__ __forceinline__ unsigned long long r_fmix64(unsigned long long x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ float r_noise_normal(unsigned long long key0, unsigned int a, unsigned int lane, unsigned int ordinal) {
+  const unsigned long long h = r_fmix64(key0 ^ (((unsigned long long)a << 40) | ((unsigned long long)lane << 20) | ordinal) * 0x9E3779B97F4A7C15ull);
+  const float u1 = ((float)(unsigned int)(h >> 40) + 0.5f) * (1.0f / 16777216.0f); // (0, 1): 24 bits each
+  const float u2 = ((float)(unsigned int)(h & 0xFFFFFFu) + 0.5f) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+__device__ __forceinline__ unsigned long long tsc_noise_key0(unsigned long long seed, int global_replica, int t_done) {
+  return r_fmix64(seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)(unsigned int)global_replica << 32) | (unsigned int)t_done));
+}
+#define TSC_PARKED(S, r) ((S).any_parked && (S).parked[(r)])
 // last tie-break of Cross::canPass between vehicles `vid` and `fvid` of the flow set at `vbase`: true = `vid` goes first
 __device__ __forceinline__ bool tsc_goes_first(const DevNet &N, int vbase, int vid, int fvid) {
   if (N.veh_prio) {
@@ -155,6 +177,11 @@ __device__ __forceinline__ bool tsc_goes_first(const DevNet &N, int vbase, int v
 
 struct DevState {
   int R, RS; // replicas, row stride (R rounded up to 64)
+  // tsc_park on the list family (round 5): parked[r] != 0 -- every kernel that walks replica r's state treats its lane as it
+  // treats a lane beyond R: nothing moves, nothing is written, valid_dev = 0 -- until a reset that selects r.  any_parked: the
+  // handle has parked replicas at all (a kernel argument: handles that never park pay no load for the test).
+  int any_parked;
+  unsigned char *parked; // [RS]
   int n_slots; // total vehicle slots per replica (rows of the tiled slot arrays)
   // per slot [S_total * RS]
   // One vehicle = {dist, speed} (16 bytes, ping-pong) + {aux, blk} (8 bytes) + tag (4 bytes), the
@@ -174,6 +201,8 @@ struct DevState {
   int *fz; // [lane][replica] k_enum's standing block: fa | fb << 16 (slots (fa, fb] are skipped)
   double *lane_sum;
   unsigned long long *lane_in_bits; // 3 predicate bits per incoming-window bin (visibility <= 16)
+  float *lane_in_val; // [n_lanes * visibility * RS] (observation noise only, else null): the VALUE of every bin of the
+                      // incoming window, x = -1 + sum(1 + s / s_max) (retriever.py:20-52), what the noise is added to
   unsigned int *lane_out_bits;
   // per agent [n_agents * RS]
   int *cur_idx, *top, *changed;
@@ -206,6 +235,8 @@ struct DevCfg {
   int r_force;    // bit 0: every sub-step takes the two-phase hand-off path; bit 1: the measure phase walks the lists
   int r_task_cap; // cross tasks per sub-step held in LDS (<= R_TASKS); beyond: the vehicle scans its crosses serially
   int r_margin;   // records of headroom below which a replica asks for the migration to the list family
+  int r_small_down; // two-class handles: a replica of the full-size class that needs fewer records than this goes back to the
+                    // small class (its capacity less twice R_CLS_MARGIN); 0: the handle has no small class
   double interval, veh_size_min_gap, flickering_coef;
   // device-side observation noise (tsc_config_t::obs_noise_std / _seed; resident family): 0 = off
   float obs_noise_std;

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64, 6) void k_enum(DevNet N, DevState S, DevCfg C, 
   const bool IS_LINK = row >= N.n_lanes; // rows: the lanes, then the lane-links in groups of TSC_ENUM_LB
   const int lane = threadIdx.x;
   const int r = rb * 64 + lane;
-  const bool own_valid = r < S.R;
+  const bool own_valid = r < S.R && !TSC_PARKED(S, r);
   if (row == 0 && own_valid) S.t[r] += 1; // the step index being executed from here on (the first kernel of a sub-step)
   if (IS_LINK) {
     // Round 4: a wavefront takes TSC_ENUM_LB lane-links, their counts requested together.  Three quarters of the rows
@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(256) void k_commit(DevNet N, DevState S, DevCfg C, 
   if (!map_block(n_rb, n_dblk, rb, dblk)) return;
   int d = __builtin_amdgcn_readfirstlane(dblk * (int)blockDim.y + (int)threadIdx.y);
   int r = rb * 64 + threadIdx.x;
-  if (d >= N.n_drv || r >= S.R) return;
+  if (d >= N.n_drv || r >= S.R || TSC_PARKED(S, r)) return;
   const bool is_link = d >= N.n_lanes;
   const int sb = N.drv_slot_base[d];
   const int cap = N.drv_cap[d];
@@ -1658,6 +1658,7 @@ __global__ void k_reset_replica(DevNet N, DevState S, DevCfg C, const unsigned c
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.R) return;
   if (mask && !mask[r]) return;
+  if (S.parked) S.parked[r] = 0; // (a reset starts a parked replica again)
   int restarts = first ? 0 : S.restarts[r] + (C.sequential_sets ? 1 : 0);
   S.restarts[r] = restarts;
   int set = (C.set_offset + r + restarts) % N.n_sets;
@@ -1683,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_phase(DevNet N, DevState S, DevCfg C, c
   if (!map_block(n_rb, n_ablk, rb, ablk)) return;
   int a = __builtin_amdgcn_readfirstlane(ablk * (int)blockDim.y + (int)threadIdx.y);
   int r = rb * 64 + threadIdx.x;
-  if (a >= N.n_agents || r >= S.R) return;
+  if (a >= N.n_agents || r >= S.R || TSC_PARKED(S, r)) return;
   int act = actions[(size_t)r * N.n_agents + a];
   if (act == -1) return; // signal left untouched (no switch_phase call in the reference)
   int np_ = N.agent_n_phases[a];
@@ -1764,6 +1765,11 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
   int q = 0;
   double sum = 0;
   double bin_size = bins > 0 ? len / bins : 1.0;
+  // observation noise (round 5: on this family too): the value of every incoming-window bin, -1 + sum(1 + s / s_max) in
+  // vehicle order (f32: the noise is compared with it, nothing else reads it); this thread owns the lane's row of them
+  float *const val = S.lane_in_val ? S.lane_in_val + ((size_t)l * vis) * S.RS + r : nullptr;
+  if (val)
+    for (int b = 0; b < vis; b++) val[(size_t)b * S.RS] = -1.0f;
   const double inv_bin = 1.0 / bin_size;
   constexpr int MU = 4; // records requested together (8: +7 % time on the 16x16 grid -- 82 VGPRs, fewer wavefronts in flight)
   for (int i0 = 0; __builtin_amdgcn_ballot_w64(i0 < n); i0 += MU) {
@@ -1802,6 +1808,7 @@ __global__ __launch_bounds__(64 * MEASURE_WAVES) void k_measure(DevNet N, DevSta
       if (idx < vis) out_one |= 1u << idx;
       if (idx >= in0) {
         const unsigned int bit = 1u << (idx - in0);
+        if (val) val[(size_t)(idx - in0) * S.RS] += (float)(1.0 + (speed == 0.0 ? 0.0 : round6(speed) / maxspd));
         if (in_one & bit) {
           in_two |= bit;
         } else {
@@ -1986,7 +1993,7 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
   int r = rb * 64 + threadIdx.x;
   const int wy = threadIdx.y, lx = threadIdx.x;
   live = live && a < N.n_agents;
-  const bool mine = live && r < S.R;
+  const bool mine = live && r < S.R && !TSC_PARKED(S, r);
   const int A = N.n_agents, vis = C.visibility;
   int cur = 0, np_ = 1;
   // Round 4: the per-lane words of the signal's incoming and outgoing lanes are REQUESTED together, before the first one
@@ -2007,8 +2014,53 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
       lq[k] = S.lane_q[IDX(l)];
       ln[k] = S.lane_n[IDX(l)];
       lsum[k] = S.lane_sum[IDX(l)];
-      lbits[k] = out.obs_dev ? S.lane_in_bits[IDX(l)] : 0ull;
+      lbits[k] = (out.obs_dev || out.phase_scores_dev) ? S.lane_in_bits[IDX(l)] : 0ull;
       lon[k] = S.lane_n[IDX(N.agent_out_lanes[ob + (k < n_out ? k : n_out - 1)])];
+    }
+  }
+  // ---- per-phase scores of the rule-based controllers (tsc_step_out_t::phase_scores_dev; reference
+  //      controllers/controllers.py:93-112,153-178,227-242).  The movements of a phase are wave-uniform (one signal per
+  //      wavefront): scalar loads, a loop over the set bits of the phase's lane mask; the per-lane counts travel packed
+  //      eight bits each in 64-bit registers (no indexed register arrays); the row of 60 shorts leaves as 15 8-byte stores.
+  if (out.phase_scores_dev && mine && N.agent_moves) {
+    unsigned long long c_in[2] = {0ull, 0ull}, c_z[2] = {0ull, 0ull}, c_out[2] = {0ull, 0ull};
+#pragma unroll
+    for (int k = 0; k < MI; k++) {
+      if (k < n_inc) {
+        const unsigned long long b_ = lbits[k];
+        c_in[k >> 3] |= (unsigned long long)__builtin_popcountll(b_ & 0x1249249249249249ull) << (8 * (k & 7));
+        c_z[k >> 3] |= (unsigned long long)__builtin_popcountll((b_ >> 1) & 0x1249249249249249ull) << (8 * (k & 7));
+      }
+      if (k < n_out)
+        c_out[k >> 3] |= (unsigned long long)__builtin_popcount(S.lane_out_bits[IDX(N.agent_out_lanes[ob + k])]) << (8 * (k & 7));
+    }
+    const int np_s = N.agent_n_phases[a];
+    unsigned long long *dst = (unsigned long long *)(out.phase_scores_dev + ((size_t)r * A + a) * (TSC_MAX_PHASES * 3));
+    unsigned long long acc = 0ull;
+    int fill = 0; // bits of `acc` in use
+    for (int p_ = 0; p_ < TSC_MAX_PHASES; p_++) {
+      unsigned long long w3 = 0ull; // the phase's three scores, 16 bits each
+      if (p_ < np_s) {
+        const uint4 mv = N.agent_moves[a * TSC_MAX_AGENT_PHASES + p_];
+        const unsigned long long sel = (unsigned long long)mv.y | ((unsigned long long)mv.z << 32);
+        int s_q = 0, s_f = 0, s_p = 0;
+        for (unsigned int m_ = mv.x & 0xFFFFu; m_; m_ &= m_ - 1u) {
+          const int i = __builtin_ctz(m_), j = (int)((sel >> (4 * i)) & 15ull);
+          const int n_in = (int)((c_in[i >> 3] >> (8 * (i & 7))) & 255ull), n_z = (int)((c_z[i >> 3] >> (8 * (i & 7))) & 255ull);
+          const int n_o = (int)((c_out[j >> 3] >> (8 * (j & 7))) & 255ull);
+          s_q += n_z;
+          s_f += n_in;
+          s_p += n_in > n_o ? n_in - n_o : n_o - n_in;
+        }
+        w3 = (unsigned long long)(unsigned short)s_q | ((unsigned long long)(unsigned short)s_f << 16) | ((unsigned long long)(unsigned short)s_p << 32);
+      }
+      acc |= w3 << fill;
+      fill += 48;
+      if (fill >= 64) {
+        *dst++ = acc;
+        fill -= 64;
+        acc = fill ? (w3 >> (48 - fill)) : 0ull;
+      }
     }
   }
   if (mine) {
@@ -2092,6 +2144,8 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
   // (round 4: a row's padding -- some 190 of an observation row's 324 values -- is not written value by value by the row's
   //  thread: the wavefront clears its 64 rows with 16-byte LDS stores first; and a lane's kept bins are walked by their
   //  bits, not by testing all `visibility` bins)
+  const bool noisy = C.obs_noise_std > 0.0f && S.lane_in_val != nullptr && out.obs_dev != nullptr;
+  const unsigned long long nkey0 = (noisy && mine) ? tsc_noise_key0(C.obs_noise_seed, C.replica_base + r, S.t[r] + 1) : 0ull;
   auto clear_rows = [&]() {
     uint4 *z = (uint4 *)(rows_lds + (size_t)wy * 64 * row_stride); // (64 x row_stride bytes: a multiple of 256)
     for (int i = lx; i < 4 * row_stride; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -2122,10 +2176,16 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
           }
           const unsigned long long bits = lbits[k];
           unsigned long long sel = bits & ~(bits >> 1) & bin0;
+          unsigned int ord = 0;
           while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
             const int b3 = __builtin_ctzll(sel);
             sel &= sel - 1ull;
-            acc |= ((bits >> (b3 + 2)) & 1ull) << pos; // (value 1: symbol 01; value 0: 00)
+            unsigned long long one = (bits >> (b3 + 2)) & 1ull;
+            if (noisy) { // _add_gaussian_noise (observations.py:72-88): one draw per surviving entry, clip, truncate
+              const float v_ = S.lane_in_val[((size_t)N.agent_inc_lanes[ib + k] * vis + b3 / 3) * S.RS + r];
+              one = (v_ + C.obs_noise_std * r_noise_normal(nkey0, (unsigned int)a, (unsigned int)k, ord++) >= 1.0f) ? 1ull : 0ull;
+            }
+            acc |= one << pos; // (value 1: symbol 01; value 0: 00)
             pos += 2;
             if (pos >= 32) {
               row[wi++] = (unsigned int)acc;
@@ -2161,10 +2221,16 @@ __global__ __launch_bounds__(64 * AGENT_WAVES) void k_agent(DevNet N, DevState S
           for (int j = 0; j < TSC_LANE_STATIC; j++) row[w++] = (unsigned char)(N.lane_static[l * TSC_LANE_STATIC + j] + 1);
           const unsigned long long bits = lbits[k];
           unsigned long long sel = bits & ~(bits >> 1) & bin0;
+          unsigned int ord = 0;
           while (sel) { // kept iff value > 0; value = trunc(clip(v, 0, 1)); in bin order
             const int b3 = __builtin_ctzll(sel);
             sel &= sel - 1ull;
-            row[w++] = ((bits >> b3) & 4ull) ? 2 : 1;
+            bool one = ((bits >> b3) & 4ull) != 0;
+            if (noisy) {
+              const float v_ = S.lane_in_val[((size_t)l * vis + b3 / 3) * S.RS + r];
+              one = v_ + C.obs_noise_std * r_noise_normal(nkey0, (unsigned int)a, (unsigned int)k, ord++) >= 1.0f;
+            }
+            row[w++] = one ? 2 : 1;
           }
         }
       }
@@ -2332,7 +2398,7 @@ __global__ void k_local_rewards(DevNet N, DevState S, tsc_step_out_t out, int n_
   int rb, ab;
   if (!map_block(n_rb, n_ablk, rb, ab)) return;
   const int r = rb * 64 + (int)threadIdx.x, a = ab * (int)blockDim.y + (int)threadIdx.y;
-  if (r >= S.R || a >= N.n_agents) return;
+  if (r >= S.R || a >= N.n_agents || TSC_PARKED(S, r)) return;
   double rew = S.agent_local[IDX(a)];
   for (int k = N.agent_nbr_ptr[a]; k < N.agent_nbr_ptr[a + 1]; k++) rew += N.agent_nbr_w[k] * S.agent_local[IDX(N.agent_nbr[k])];
   if (out.local_reward_dev) out.local_reward_dev[(size_t)r * N.n_agents + a] = (float)rew;
@@ -2344,6 +2410,10 @@ __global__ void k_local_rewards(DevNet N, DevState S, tsc_step_out_t out, int n_
 __global__ void k_stats(DevNet N, DevState S, DevCfg C, tsc_step_out_t out) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.R) return;
+  if (TSC_PARKED(S, r)) { // (tsc_park: the replica's rows are not written; the caller is told)
+    if (out.valid_dev) out.valid_dev[r] = 0;
+    return;
+  }
   const int A = N.n_agents;
   long long nq_all = S.nq_all[r], nveh_all = 0;
   S.nq_all[r] = 0;
@@ -2431,6 +2501,11 @@ __global__ void k_snapshot(DevNet N, DevState S, int rep, int cap, int *count, i
   }
 }
 
+__global__ void k_park_list(DevState S, const unsigned char *mask) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < S.R && mask[r]) S.parked[r] = 1;
+}
+
 // Uniformly random allowed action per (replica, agent): one launch instead of a chain of
 // tensor ops (reference RandomController, controllers.py:245-268).
 __global__ void k_random_valid(DevState S, DevCfg C, int A, const unsigned char *mask, unsigned long long seed,
@@ -2454,6 +2529,78 @@ __global__ void k_random_valid(DevState S, DevCfg C, int A, const unsigned char 
       break;
     }
   actions[i] = act;
+}
+
+// The reference's rule-based controllers (pytsc/controllers/controllers.py:26-268) for every (replica, signal) in one
+// launch, from what the step just wrote: phase [R, A, 3] (index, time on it, changed) and the per-phase scores [R, A,
+// TSC_MAX_PHASES, 3] (stopped vehicles, vehicles, pressure: tsc_step_out_t::phase_scores_dev).  Allowable phases:
+// TLSFreePhaseSelectLogic / TLSRoundRobinPhaseSelectLogic (common/traffic_signal.py:329-404), as the action masks of the
+// step.  kind / p0..p2: include/pytsc_amd.h, TSC_CTRL_*.
+__global__ void k_controller(DevNet N, DevState S, DevCfg C, int kind, int p0, int p1, int p2, unsigned long long seed,
+                             unsigned long long draw, const int *phase, const short *scores, int *actions) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int A = N.n_agents;
+  if (i >= S.R * A) return;
+  const int a = i % A;
+  const int cur = phase[(size_t)i * 3], top = phase[(size_t)i * 3 + 1];
+  const int np_ = N.agent_n_phases[a];
+  const int *green = N.agent_phase_green + a * TSC_MAX_AGENT_PHASES;
+  const int nxt = cur + 1 == np_ ? 0 : cur + 1;
+  const bool is_green = green[cur] != 0;
+  // allowable phase switches (bit p): green: t < min {cur}; min <= t < max {cur, next}; t == max {next}; yellow: free --
+  // every green phase but the one just left; round robin -- the next one
+  unsigned int allow = 0;
+  if (is_green) {
+    const int mn = N.agent_phase_min[a * TSC_MAX_AGENT_PHASES + cur], mx = N.agent_phase_max[a * TSC_MAX_AGENT_PHASES + cur];
+    if (top < mn) allow = 1u << cur;
+    else if (top < mx) allow = (1u << cur) | (1u << nxt);
+    else if (top == mx) allow = 1u << nxt;
+  } else if (C.round_robin) {
+    allow = 1u << nxt;
+  } else {
+    for (int k = 0; k < np_; k++)
+      if (green[k] && k != cur - 1) allow |= 1u << k;
+  }
+  // splitmix64 of (seed, call, GLOBAL replica * A + agent), as k_random_valid
+  unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (draw + 1) +
+                         0xbf58476d1ce4e5b9ull * ((unsigned long long)C.replica_base * (unsigned long long)A + (unsigned long long)(i + 1));
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  const short *sc = scores ? scores + (size_t)i * (TSC_MAX_PHASES * 3) : nullptr;
+  int target = nxt;
+  if (kind == TSC_CTRL_FIXED_TIME) {
+    target = (is_green && top < p0) ? cur : nxt; // (controllers.py:39-54)
+  } else if (kind == TSC_CTRL_GREEDY || kind == TSC_CTRL_MAX_PRESSURE || kind == TSC_CTRL_RANDOM) {
+    if (is_green || kind == TSC_CTRL_RANDOM) {
+      // the allowable phases with the largest score (random: every allowable phase), one of them uniformly at random
+      const int col = kind == TSC_CTRL_GREEDY ? 0 : 2;
+      int best = -1;
+      unsigned int ties = 0;
+      for (int k = 0; k < np_ && k < TSC_MAX_PHASES; k++)
+        if ((allow >> k) & 1u) {
+          const int v = kind == TSC_CTRL_RANDOM ? 0 : (int)sc[k * 3 + col];
+          if (v > best) {
+            best = v;
+            ties = 1u << k;
+          } else if (v == best) ties |= 1u << k;
+        }
+      const int n_t = __builtin_popcount(ties);
+      if (n_t > 0) {
+        int pick = (int)(((z >> 32) * (unsigned long long)n_t) >> 32);
+        unsigned int t = ties;
+        while (pick-- > 0) t &= t - 1u;
+        target = __builtin_ctz(t);
+      }
+    }
+  } else if (kind == TSC_CTRL_SOTL) { // (controllers.py:200-242; p0 = theta, p1 = mu, p2 = phi_min)
+    if ((allow >> cur) & 1u) {
+      int ng = nxt + 1 == np_ ? 0 : nxt + 1; // next green phase index: (cur + 2) % n_phases
+      const int red = ng < TSC_MAX_PHASES ? (int)sc[ng * 3 + 1] : 0, grn = cur < TSC_MAX_PHASES ? (int)sc[cur * 3 + 1] : 0;
+      target = (top >= p2 && !(grn > 0 && grn < p1) && red >= p0) ? nxt : cur;
+    } else target = nxt;
+  }
+  actions[i] = C.action_space == TSC_ACT_PHASE_SWITCH ? (target != cur ? 1 : 0) : target;
 }
 
 __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total) {

@@ -37,7 +37,7 @@ class TscNet(C.Structure):
         ("agent_out_ptr", _pi), ("agent_out_lanes", _pi),
         ("agent_nbr_ptr", _pi), ("agent_nbr", _pi), ("agent_nbr_w", _pd),
         ("route_ptr", _pi), ("route_drv", _pi),
-        ("tmpl", _pd),
+        ("tmpl", _pd), ("agent_phase_moves", _pu),
     ]
 
 
@@ -75,6 +75,7 @@ class TscStepOut(C.Structure):
         ("stats_dev", C.c_void_p), ("agent_stats_dev", C.c_void_p),
         ("phase_dev", C.c_void_p), ("local_reward64_dev", C.c_void_p),
         ("global_reward64_dev", C.c_void_p), ("valid_dev", C.c_void_p),
+        ("phase_scores_dev", C.c_void_p),
     ]
 
 
@@ -171,6 +172,24 @@ class Tables:
                     w.append(gamma ** k)
             nbr_l.append(nb)
             nbr_w.append(w)
+        # the movements of every phase (include/pytsc_amd.h, tsc_net_t::agent_phase_moves): which of the signal's incoming
+        # lanes a phase serves and, per such lane, the LAST outgoing lane its dict entry lists (controllers.py:153-178)
+        moves = np.zeros((A, MAX_AGENT_PHASES, 4), dtype=np.uint32)
+        moves_ok = all(len(l) <= 16 for l in inc_l) and all(len(l) <= 16 for l in out_l)
+        if moves_ok:
+            for a, ts_id in enumerate(rn.agent_ids):
+                ts = parser.traffic_signals[ts_id]
+                inc_pos = {l: k for k, l in enumerate(ts["incoming_lanes"])}
+                out_pos = {l: k for k, l in enumerate(ts["outgoing_lanes"])}
+                for k, raw in enumerate(ts["phases"]):
+                    sel = 0
+                    for lane, outs in ts["phase_to_inc_out_lanes"].get(raw, {}).items():
+                        i = inc_pos[lane]
+                        moves[a, k, 0] |= np.uint32(1 << i)
+                        sel |= (out_pos[outs[-1]] & 15) << (4 * i)
+                    moves[a, k, 1] = np.uint32(sel & 0xFFFFFFFF)
+                    moves[a, k, 2] = np.uint32(sel >> 32)
+        self.phase_moves = moves if moves_ok else None
         inc_ptr, inc_flat = _csr(inc_l)
         out_ptr, out_flat = _csr(out_l)
         nbr_ptr, nbr_flat = _csr(nbr_l)
@@ -201,6 +220,7 @@ class Tables:
             a(inc_ptr, _pi), a(inc_flat, _pi), a(out_ptr, _pi), a(out_flat, _pi),
             a(nbr_ptr, _pi), a(nbr_flat, _pi), a(nbr_wflat, _pd),
             a(route_ptr, _pi), a(route_drv, _pi), a(tmpl, _pd),
+            a(moves.reshape(-1), _pu) if moves_ok else None,
         )
         self.drv_cap = drv_cap
         self.drv_length = drv_length

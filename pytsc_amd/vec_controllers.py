@@ -83,15 +83,28 @@ def _argmax_random_ties(score, allow, generator=None):
     return (u * tie).argmax(-1)
 
 
+# The three per-phase scores.  `counts`: either the step's `phase_scores` output [R, A, 20, 3] int16 (round 5: the step
+# computes them where it assembles the observation rows -- tsc_step_out_t::phase_scores_dev; nothing larger than [R, A, P]
+# exists on this side) or the per-lane window counts [R, L, 3] of tsc_lane_window_counts (the dense formulas of rounds 3-4:
+# a second pass over the state and, for the pressure, an [R, A, P, L] tensor -- 1 GB per call on the 4x4 @ 4096, out of
+# memory on the 16x16; kept as the independent restatement the fused scores are tested against at small R).
+def _fused(ctx, counts, col):
+    return counts[:, :, : ctx.P, col].float() if counts.dim() == 4 else None
+
+
 def queue_scores(ctx, counts):
     """[R, A, P]: stopped vehicles (bins == 0.0) in the incoming windows of each phase's lanes
     (GreedyController._compute_queue_for_phase, controllers.py:93-112)."""
-    return torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 0].float())
+    f = _fused(ctx, counts, 0)
+    return f if f is not None else torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 0].float())
 
 
 def pressure_scores(ctx, counts):
     """[R, A, P]: MaxPressureController._compute_pressure_for_phase (controllers.py:153-178), including its
     quirk that only the LAST outgoing lane of a movement is counted."""
+    f = _fused(ctx, counts, 2)
+    if f is not None:
+        return f
     occ_in = counts[..., 1].float()   # [R, L]
     occ_out = counts[..., 2].float()  # [R, L]
     R = occ_in.shape[0]
@@ -102,7 +115,8 @@ def pressure_scores(ctx, counts):
 def flow_scores(ctx, counts):
     """[R, A, P]: vehicles (bins >= 0) in the incoming windows of each phase's lanes
     (SOTLController._compute_flow_for_phase, controllers.py:227-242)."""
-    return torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 1].float())
+    f = _fused(ctx, counts, 1)
+    return f if f is not None else torch.einsum("apl,rl->rap", ctx.phase_inc, counts[..., 1].float())
 
 
 def greedy(ctx, buf, counts, generator=None):

@@ -23,7 +23,9 @@ class VecEngine:
 
     def __init__(self, tables, device=0, want=("obs", "state", "mask", "local_reward", "global_reward",
                                               "done", "terminated", "stats", "agent_stats", "phase",
-                                              "local_reward64", "global_reward64", "valid"), family="auto"):
+                                              "local_reward64", "global_reward64", "valid", "phase_scores"), family="auto"):
+        if getattr(tables, "phase_moves", None) is None:  # (a signal with more than 16 lanes on a side: no fused scores)
+            want = tuple(k for k in want if k != "phase_scores")
         if not torch.cuda.is_available():
             raise RuntimeError("pytsc_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _lib.load()
@@ -69,13 +71,16 @@ class VecEngine:
             "global_reward64": ((R,), torch.float64),
             # 1: the replica's rows are those of the call just made; 0: it is stalled (include/pytsc_amd.h, valid_dev)
             "valid": ((R,), torch.uint8),
+            # per-phase scores of the rule-based controllers (include/pytsc_amd.h, tsc_step_out_t::phase_scores_dev):
+            # [..., 0] stopped vehicles, [..., 1] vehicles in the incoming windows, [..., 2] pressure of the phase's movements
+            "phase_scores": ((R, A, 20, 3), torch.int16),
         }
         self.buf = {k: z(*shapes[k]) for k in want}
         ptr = lambda k: self.buf[k].data_ptr() if k in self.buf else None
         self.out = TscStepOut(ptr("obs"), ptr("state"), ptr("mask"), ptr("local_reward"),
                               ptr("global_reward"), ptr("done"), ptr("terminated"), ptr("stats"),
                               ptr("agent_stats"), ptr("phase"), ptr("local_reward64"),
-                              ptr("global_reward64"), ptr("valid"))
+                              ptr("global_reward64"), ptr("valid"), ptr("phase_scores"))
 
     @property
     def family(self):
@@ -184,6 +189,34 @@ class VecEngine:
                    "tsc_random_valid_actions")
         return out
 
+    CONTROLLERS = {"fixed_time": 0, "greedy": 1, "max_pressure": 2, "sotl": 3, "random": 4}
+
+    def controller_actions(self, kind, buf=None, params=(), seed=0, out=None):
+        """[R, A] int32: the reference's rule-based controller `kind` (pytsc/controllers/controllers.py:26-268) for every
+        replica and signal in ONE launch (tsc_controller_actions), from the `phase` and `phase_scores` outputs of the step
+        just made (the engine must have been created with both in `want`).  params: fixed_time (green_time = 25,);
+        sotl (theta = 3, mu = 4, phi_min = 5)."""
+        buf = self.buf if buf is None else buf
+        k = self.CONTROLLERS[kind]
+        p = list(params) + [0, 0, 0]
+        if kind == "fixed_time" and not params:
+            p[0] = 25
+        if kind == "sotl" and not params:
+            p[:3] = [3, 4, 5]
+        if out is None:
+            out = torch.empty((self.R, self.A), dtype=torch.int32, device=self.device)
+        sc = buf.get("phase_scores")
+        _lib.check(self.lib.tsc_controller_actions(self.h, k, int(p[0]), int(p[1]), int(p[2]), int(seed), buf["phase"].data_ptr(),
+                                                   sc.data_ptr() if sc is not None else None, out.data_ptr(),
+                                                   torch.cuda.current_stream(self.device).cuda_stream), "tsc_controller_actions")
+        return out
+
+    def class_counts(self):
+        """(replicas in the small class, in the full-size class) of a two-class handle (tsc_class_counts)."""
+        c = (C.c_int32 * 2)()
+        _lib.check(self.lib.tsc_class_counts(self.h, c), "tsc_class_counts")
+        return int(c[0]), int(c[1])
+
     def replica_counts(self):
         """[R, 3] int32: vehicles entered so far, running, finished (entered == running + finished)."""
         out = torch.zeros((self.R, 3), dtype=torch.int32, device=self.device)
@@ -196,7 +229,7 @@ class VecEngine:
         _lib.check(self.lib.tsc_errors(self.h, C.byref(e)), "tsc_errors")
         return e.value
 
-    PATH_KEYS = ("two_phase", "walk", "serial_scan", "conflict", "dirty", "stalled")
+    PATH_KEYS = ("two_phase", "walk", "serial_scan", "conflict", "dirty", "stalled", "class_redo", "class_change")
 
     def path_counts(self):
         """dict: how often the resident family took each of its data-dependent paths since create

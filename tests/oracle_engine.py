@@ -19,7 +19,10 @@ class OracleEngine:
     def _buf(self, out):
         names = ("obs", "state", "mask", "local_reward", "global_reward", "done", "terminated", "stats",
                  "agent_stats", "phase", "local_reward64", "global_reward64")
-        return {k: torch.from_numpy(getattr(out, k).copy()) for k in names}
+        b = {k: torch.from_numpy(getattr(out, k).copy()) for k in names}
+        if getattr(self.tables, "phase_moves", None) is not None:
+            b["phase_scores"] = torch.from_numpy(out.phase_scores.copy())
+        return b
 
     def reset(self, mask=None, sets=None):
         self.o.reset(None if mask is None else np.asarray(mask), None if sets is None else np.asarray(sets))

@@ -18,7 +18,7 @@ def test_header_symbols_are_exported():
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.tsc_abi_version() == 4
+    assert lib.tsc_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -46,6 +46,29 @@ def _run_controllers(case, gpu, R=3, family="auto"):
         counts = eng.lane_window_counts()
         allow = ctx.allowable(buf)
         q, pr, fl = vc.queue_scores(ctx, counts), vc.pressure_scores(ctx, counts), vc.flow_scores(ctx, counts)
+        # round 5: the same three scores as the STEP computes them (tsc_step_out_t::phase_scores_dev: oracle on the CPU, the
+        # signal phase of kr_step / k_agent on the GPU) against the reference's controllers' own numbers
+        ps = buf["phase_scores"]
+        fq, fp, ff = vc.queue_scores(ctx, ps), vc.pressure_scores(ctx, ps), vc.flow_scores(ctx, ps)
+        for r in (0, R - 1):
+            assert np.array_equal(fq[r].cpu().numpy()[:, :P], exp["x_score_queue"][s]), (s, "fused queue")
+            assert np.array_equal(fp[r].cpu().numpy()[:, :P], exp["x_score_pressure"][s]), (s, "fused pressure")
+            assert np.array_equal(ff[r].cpu().numpy()[:, :P], exp["x_score_flow"][s]), (s, "fused flow")
+        assert int(ps[:, :, P:].abs().sum()) == 0  # phases the signals do not have: 0
+        if gpu:  # ... and the fused controller launch (tsc_controller_actions) on those scores
+            kind_ = CTRL_CASES[case]
+            fa = eng.controller_actions(kind_, buf, seed=s)[0].cpu().numpy()
+            if kind_ == "sotl":
+                assert fa.tolist() == exp["actions"][s].tolist(), (s, "fused sotl")
+            else:
+                sc_ = (fq if kind_ == "greedy" else fp)[0]
+                sc_ = torch.where(allow[0], sc_, torch.full_like(sc_, float("-inf"))).cpu().numpy()
+                cur_ = buf["phase"][0, :, 0].cpu().numpy()
+                for a in range(tables.n_agents):
+                    if bool(ctx.green[a, cur_[a]]):
+                        assert sc_[a, fa[a]] == sc_[a].max(), (s, a, "fused argmax")
+                    else:
+                        assert fa[a] == (cur_[a] + 1) % int(ctx.n_phases[a])
         for r in (0, R - 1):
             assert np.array_equal(allow[r].cpu().numpy().astype(np.int8)[:, :P], exp["x_allow"][s]), (s, "allow")
             assert np.array_equal(q[r].cpu().numpy()[:, :P], exp["x_score_queue"][s]), (s, "queue")
