@@ -508,6 +508,12 @@ def worker(args):
         dev, A = "cpu", 16
         eng = _StubEngine(R, A)
         t_tab = t_create = 0.0
+        if args.stub_tables:  # (tests: what every rank of an N-GPU job does before it can create its handle)
+            t_tab = time.perf_counter()
+            tb_ = workload_tables(args.rows, args.cols, R, rank * R, args.rate, flow_sets_of(args), args.scenario)
+            t_tab = time.perf_counter() - t_tab
+            assert tb_.flows.n_sets == flow_sets_of(args)
+            del tb_
     else:
         from pytsc_amd.vec_env import VecEngine
 
@@ -520,7 +526,10 @@ def worker(args):
         tables.cfg.replica_base = rank * R  # the policy's draws follow the GLOBAL replica index, like the flow sets
         A = tables.n_agents
         t_create = time.perf_counter()
-        eng = VecEngine(tables, device=local_rank, want=tuple(args.outputs.split(",")), family=args.family)
+        want = tuple(args.outputs.split(","))
+        if args.policy != "random":  # the rules read the phase state and the per-phase scores of the step just made
+            want = want + tuple(k for k in ("phase", "phase_scores") if k not in want)
+        eng = VecEngine(tables, device=local_rank, want=want, family=args.family)
         t_create = time.perf_counter() - t_create
     red_dev = dev if (world_size > 1 and not args.stub and not args.one_gpu_rehearsal) else "cpu"
     torch.manual_seed(0)
@@ -528,8 +537,11 @@ def worker(args):
     acts = torch.empty((R, A), device=dev, dtype=torch.int32)
 
     def policy(mask):
-        # uniform among mask-valid actions, on device, one launch (tsc_random_valid_actions)
-        return eng.random_valid_actions(mask, seed=1234, out=acts)
+        # uniform among mask-valid actions, on device, one launch (tsc_random_valid_actions) -- or one of the reference's
+        # rule-based controllers, also one launch (tsc_controller_actions, from the step's phase state and per-phase scores)
+        if args.policy == "random" or args.stub:
+            return eng.random_valid_actions(mask, seed=1234, out=acts)
+        return eng.controller_actions(args.policy, seed=1234, out=acts)
 
     n_env_steps = 0
 
@@ -569,6 +581,13 @@ def worker(args):
     v1 = eng.mean_vehicles()
     errors = eng.errors()
     stalled = 0 if args.stub else eng.path_counts()["stalled"]
+    # two-class handles (include/pytsc_amd.h, tsc_class_counts): where the replicas are at the end of the timed region
+    classes = None
+    if not args.stub and hasattr(eng, "class_counts"):
+        pc = eng.path_counts()
+        cs, cb = eng.class_counts()
+        classes = {"small_class_512_threads_two_per_cu": cs, "full_size_class": cb,
+                   "class_changes_since_create": pc.get("class_change"), "steps_redone_by_the_full_size_launch": pc.get("class_redo")}
     if args.dump_state and not args.stub:
         # what this rank's replicas look like right behind the timed region (tests: a sharded job == the unsharded one)
         import numpy as np
@@ -635,6 +654,35 @@ def worker(args):
     # start-up of the slowest rank (every rank generates its own demands and uploads its own tables)
     t_tab = sharding.max_over_ranks(t_tab, device=red_dev)
     t_create = sharding.max_over_ranks(t_create, device=red_dev)
+    # ---- the reference's rule-based controllers driving the same workload (N = 1 extras): one states[]
+    #      entry per rule -- an engine with the phase state and the per-phase scores among its outputs, restarted, rolled
+    #      forward like the timed region (150 + warm-up env steps) under that rule, then the same number of timed steps
+    policy_states = []
+    if world_size == 1 and not args.stub and not args.no_extras and not args.no_states and args.scenario == "grid" and args.policy == "random":
+        wantc = tuple(args.outputs.split(",")) + tuple(k for k in ("phase", "phase_scores") if k not in args.outputs.split(","))
+        engc = VecEngine(tables, device=local_rank, want=wantc, family=args.family)
+        for kind in ("random", "fixed_time", "greedy", "max_pressure", "sotl"):
+            engc.reset()
+            bc = engc.observe()
+            step_c = (lambda b: engc.random_valid_actions(b["mask"], seed=1234, out=acts)) if kind == "random" else \
+                     (lambda b, k=kind: engc.controller_actions(k, b, seed=1234, out=acts))
+            for _ in range(PREROLL_ENV_STEPS + args.warmup):
+                bc = engc.step(step_c(bc))
+            torch.cuda.synchronize(dev)
+            vc0 = engc.mean_vehicles()
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                bc = engc.step(step_c(bc))
+            torch.cuda.synchronize(dev)
+            dtc = time.perf_counter() - tc
+            policy_states.append({"policy": kind, "after_env_steps": PREROLL_ENV_STEPS + args.warmup + args.steps, "steps": args.steps,
+                                  "ms_per_step": dtc / args.steps * 1e3, "value": R * A * args.steps / dtc,
+                                  "V_a": 0.5 * (vc0 + engc.mean_vehicles()) / A, "device_errors": engc.errors(),
+                                  "note": "env + controller, both on the device: the rule's one launch (tsc_controller_actions) reads "
+                                          "the step's phase state and per-phase scores (phase_scores_dev); outputs of the timed "
+                                          "region + phase + phase_scores; from a restart, 150 + warm-up env steps under the rule"})
+            errors = max(errors, policy_states[-1]["device_errors"])
+        engc.close()
     total_units = sharding.sum_over_ranks(R * A * args.steps, device=red_dev)
     v_mean = sharding.sum_over_ranks(0.5 * (v0 + v1), device=red_dev) / world_size
     value = total_units / elapsed
@@ -674,7 +722,7 @@ def worker(args):
         else:
             distinct = getattr(tables, "distinct_demands", n_sets)
             workload_name = (f"{args.rows}x{args.cols} synthetic grid ({A} agents), Poisson {args.rate:g} veh/h per entry road, "
-                             f"{n_sets} flow sets per GPU ({distinct} distinct demands" +
+                             f"policy {args.policy}, {n_sets} flow sets per GPU ({distinct} distinct demands" +
                              (": one per replica, drawn from its global index" if n_sets == R and distinct == R else "") +
                              f"), {R} env replicas per GPU, ")
         line = {
@@ -692,6 +740,7 @@ def worker(args):
                 "flow_sets_per_gpu": None if args.stub else n_sets,
                 "distinct_demands_per_gpu": None if args.stub else getattr(tables, "distinct_demands", n_sets),
                 "startup_s": {"table_build_max_over_ranks": round(t_tab, 2), "tsc_create_max_over_ranks": round(t_create, 2)},
+                "replica_classes_after_timed_region": classes,
             },
             "roofline": {
                 # the bound the contract names for this tier; the path is NOT bandwidth-bound (the step would take ~50 us
@@ -728,6 +777,7 @@ def worker(args):
                            "left_resident_family_at_env_step": hour_state["left_resident_family_at_env_step"],
                            "share_of_replica_steps_off_resident": hour_state["share_of_replica_steps_off_resident"],
                            "mean_live_vehicles_per_replica_at_the_end": hour_state["mean_live_vehicles_per_replica_at_the_end"]})
+        states += policy_states
         if len(states) > 1:
             line["states"] = states
         line["roofline_valu"] = roofline_valu(kinfo, R, va)
@@ -760,6 +810,9 @@ def parse(argv):
                          "throughput runs); 8 = the shared sets of the bench lines of rounds 1-3")
     ap.add_argument("--scenario", default="grid", help="grid (rows x cols, Poisson demand) | jinan (BASELINE config 4)")
     ap.add_argument("--family", default="auto", help="kernel family: auto | list | resident")
+    ap.add_argument("--policy", default="random", help="what drives the env in the timed region: random (uniform among the valid "
+                    "actions, tsc_random_valid_actions) | fixed_time | greedy | max_pressure | sotl (the reference's rule-based "
+                    "controllers, one fused launch each: tsc_controller_actions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-preroll", action="store_true", help="diagnostic: time the network as started")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-step spread and the other states (N = 1 extras)")
@@ -770,6 +823,7 @@ def parse(argv):
     ap.add_argument("--cpu-warmup", type=int, default=150, help="untimed env steps of the CPU baseline")
     ap.add_argument("--outputs", default=DEFAULT_OUTPUTS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher test only
+    ap.add_argument("--stub-tables", action="store_true", help=argparse.SUPPRESS)  # ... with every rank's REAL table generation (start-up)
     ap.add_argument("--one-gpu-rehearsal", action="store_true",
                     help="tests: run the --gpus N code path with every rank on GPU 0 (gloo for the barrier / reductions)")
     ap.add_argument("--dump-state", default=None, help="tests: write <path>.rank<k>.npz with each rank's outputs behind the timed region")

@@ -235,6 +235,7 @@ struct DevCfg {
   int r_force;    // bit 0: every sub-step takes the two-phase hand-off path; bit 1: the measure phase walks the lists
   int r_task_cap; // cross tasks per sub-step held in LDS (<= R_TASKS); beyond: the vehicle scans its crosses serially
   int r_margin;   // records of headroom below which a replica asks for the migration to the list family
+  int r_small_up;   // two-class handles: the small class's capacity less R_CLS_MARGIN: a replica that needs more is the full-size class's
   int r_small_down; // two-class handles: a replica of the full-size class that needs fewer records than this goes back to the
                     // small class (its capacity less twice R_CLS_MARGIN); 0: the handle has no small class
   double interval, veh_size_min_gap, flickering_coef;

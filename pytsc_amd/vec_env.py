@@ -129,7 +129,7 @@ class VecEngine:
 
     def park(self, mask):
         """Replicas with mask[r] != 0 are skipped by every later step / observe (valid = 0) until a reset that selects them
-        (include/pytsc_amd.h, tsc_park; resident family only)."""
+        (include/pytsc_amd.h, tsc_park; both kernel families)."""
         mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         self._last_park = mask
         _lib.check(self.lib.tsc_park(self.h, C.c_void_p(mask.data_ptr()), self._stream()), "tsc_park")

@@ -48,3 +48,21 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--stub"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_eight_ranks_generate_their_own_demands_within_the_start_up_budget():
+    """`bench.py --gpus 8` must not time out before it times anything.  Eight ranks (stub engines over
+    gloo: no GPU here) each generate the 4096 demands of their shard with the array generator and build their tables --
+    what happens on the real node before tsc_create --; the line reports the slowest rank's table build."""
+    import time
+
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--replicas", "4096", "--stub",
+                        "--stub-tables"], env=_env(), capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 8
+    st = j["config"]["startup_s"]["table_build_max_over_ranks"]
+    assert 1.0 < st < 120.0, st
+    assert wall < 240.0, wall

@@ -138,6 +138,7 @@ def test_a_promoted_replica_that_restarts_goes_back_to_its_own_blob(oracle_lib):
     rng = np.random.default_rng(8)
     out = orc.observe()
     restarted = False
+    max_live = 0
     for s in range(230):
         m = out.mask
         acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
@@ -145,6 +146,7 @@ def test_a_promoted_replica_that_restarts_goes_back_to_its_own_blob(oracle_lib):
         buf = eng.step(torch.tensor(acts, device="cuda"))
         assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
         live = eng.spill_counts()["live"]
+        max_live = max(max_live, live)
         if live >= 2 and not restarted:
             mask = np.zeros(R, np.uint8)
             # (the oracle knows which replicas hold the most vehicles: those are the promoted ones)
@@ -158,7 +160,64 @@ def test_a_promoted_replica_that_restarts_goes_back_to_its_own_blob(oracle_lib):
             assert eng.spill_counts()["live"] == live - 1
             restarted = True
     assert restarted
+    # (the slot the restart gave back was handed out again -- the pool holds as many slots as it ever held replicas at once)
+    assert eng.spill_counts()["live"] >= 2 and eng.spill_counts()["slots"] == max_live, (eng.spill_counts(), max_live)
     for r in range(R):
         assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
     assert eng.errors() == 0
+    eng.close()
+
+
+def test_a_promoted_replica_that_is_parked_gives_its_slot_back(oracle_lib):
+    """tsc_park of a replica that lives in the spill pool -- the pool's launch is keyed on the slot table
+    only and went on stepping it (rows and valid_dev written by two launches).  Now the parked replica's slot is given back
+    (valid == 0, its rows untouched), the others stay exact; after a restart of the parked replica it is an ordinary replica
+    again (exact from the empty network on)."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    R = 4
+    eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, **KW), family="auto")
+    orc = oracle_lib.Oracle(_tables("syn_3x3", R, **KW))
+    rng = np.random.default_rng(8)
+    out = orc.observe()
+    parked_r, parked_at, slots_then = None, None, None
+    frozen = None
+    for s in range(260):
+        m = out.mask
+        acts = (rng.random(m.shape) * m).argmax(-1).astype(np.int32)
+        out = orc.step(acts)
+        buf = eng.step(torch.tensor(acts, device="cuda"))
+        live = eng.spill_counts()["live"]
+        if parked_r is None:
+            assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+            if live >= 1:
+                parked_r = int(np.argmax([len(orc.snapshot(r)[0]) for r in range(R)]))  # the promoted one holds the most vehicles
+                mask = np.zeros(R, np.uint8)
+                mask[parked_r] = 1
+                eng.park(torch.tensor(mask))
+                assert eng.spill_counts()["live"] == live - 1
+                slots_then = eng.spill_counts()["slots"]
+                frozen = buf["obs"][parked_r].clone()
+                parked_at = s
+        else:
+            others = [r for r in range(R) if r != parked_r]
+            if s < parked_at + 40:  # parked: not stepped, not written, the caller is told
+                assert int(buf["valid"][parked_r]) == 0 and torch.equal(buf["obs"][parked_r], frozen), s
+                assert bool(buf["valid"][others].all())
+                assert np.array_equal(buf["obs"].cpu().numpy()[others], out.obs[others]), s
+            if s == parked_at + 40:  # started again from an empty network -- in the oracle too
+                mask = np.zeros(R, np.uint8)
+                mask[parked_r] = 1
+                orc.reset(mask)
+                eng.reset(torch.tensor(mask))
+                out = orc.observe()
+                buf = eng.observe()
+                assert np.array_equal(buf["obs"].cpu().numpy(), out.obs) and bool(buf["valid"].all())
+            if s > parked_at + 40:
+                assert np.array_equal(buf["obs"].cpu().numpy(), out.obs), s
+    assert parked_r is not None
+    # (a parked handle has no stand-by any more: the others must not have run out of records in this run)
+    assert eng.errors() == 0 and orc.errors() == 0
     eng.close()

@@ -53,7 +53,10 @@ def test_batched_disrupted_config_runs_each_replica_on_its_drawn_file(oracle_lib
     env.close()
 
 
-def test_batched_multi_map_wrapper_pads_like_the_reference_and_redraws_at_the_hour(oracle_lib):
+@pytest.mark.parametrize("list_map", [None, "syn_1x3"])
+def test_batched_multi_map_wrapper_pads_like_the_reference_and_redraws_at_the_hour(oracle_lib, list_map):
+    """list_map: that map's handle runs on the LIST kernel family (round 5: tsc_park there too -- a large map such as
+    manhattan_16_3, which only that family holds, can be one of the maps)."""
     import torch
 
     from pytsc_amd.vec_env import VecTrafficSignalNetwork
@@ -63,7 +66,10 @@ def test_batched_multi_map_wrapper_pads_like_the_reference_and_redraws_at_the_ho
     kw = dict(hip={"sim_length": 60, "episode_limit": 30, "flow_rate": 900.0, "n_flow_sets": 2},
               signal={"action_space": "phase_selection", "round_robin": False})
     maps = ["syn_2x2", "syn_1x3"]
-    env = VecDomainRandomizedEPyMARLTrafficSignalNetwork(maps, n_replicas=R, seed=2, **kw)
+    mk = {list_map: {"hip": {"kernel_family": "list"}}} if list_map else None
+    env = VecDomainRandomizedEPyMARLTrafficSignalNetwork(maps, n_replicas=R, seed=2, map_kwargs=mk, **kw)
+    if list_map:
+        assert env.envs[maps.index(list_map)].engine.family == "list"
     singles = [VecTrafficSignalNetwork(m, n_replicas=R, **kw) for m in maps]
     nA = [e.n_agents for e in singles]
     assert env.max_n_agents == max(nA) == 4 and min(nA) == 3

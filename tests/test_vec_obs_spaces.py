@@ -64,7 +64,8 @@ def test_batched_lane_features_observations_and_dropout(oracle_lib):
 
 
 @pytest.mark.gpu
-def test_device_side_observation_noise_follows_the_reference_law():
+@pytest.mark.parametrize("family", ["resident", "list"])
+def test_device_side_observation_noise_follows_the_reference_law(family):
     """obs_noise_std on the batched path (reference PositionMatrix._add_gaussian_noise, common/observations.py:72-88, then the
     integer truncation of the padded row).  4096 replicas of ONE demand under one action stream are in the
     same state at every step and differ in their noise draws only, so for every (signal, lane, surviving bin):
@@ -80,7 +81,8 @@ def test_device_side_observation_noise_follows_the_reference_law():
     from pytsc_amd.vec_env import VecTrafficSignalNetwork
 
     R, std = 4096, 0.35
-    kw = dict(hip={"flow_rate": 1000.0, "n_flow_sets": 1, "seed": 11},
+    # (round 5: on the list family too -- k_measure keeps the bin values, k_agent draws)
+    kw = dict(hip={"flow_rate": 1000.0, "n_flow_sets": 1, "seed": 11, "kernel_family": family},
               signal={"action_space": "phase_selection", "round_robin": False})
     clean = VecTrafficSignalNetwork("syn_2x2", n_replicas=R, **kw)
     kwn = dict(kw, signal=dict(kw["signal"], obs_noise_std=std))
@@ -134,6 +136,6 @@ def test_device_side_observation_noise_follows_the_reference_law():
     assert min(checked_vals) < 0.5 and max(checked_vals) >= 1.0  # (bins of several vehicles, val > 1, end as 1 almost surely)
     rows = noisy.get_observations().reshape(R, -1)
     assert len(torch.unique(rows, dim=0)) > R // 2  # replicas draw independently
-    assert noisy.engine.errors() == 0
+    assert noisy.engine.errors() == 0 and noisy.engine.family == family
     for e in (clean, noisy, zero):
         e.close()
