@@ -405,10 +405,14 @@ def run_hour(eng, R, A, acts, family_requested="auto", n_steps=720, win=60):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps // win + 2)]
     fam_steps, left_at = {"resident": 0, "list": 0}, None
     pool_steps, first_promotion = 0, None
+    small_share = []  # two-class handles: share of the replicas in the small class at the start of every window
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for s in range(n_steps):
         if s % win == 0:
+            if hasattr(eng, "class_counts"):
+                cs, cb = eng.class_counts()  # (synchronises: twelve times an hour)
+                small_share.append(round(cs / max(cs + cb, 1), 3))
             ev[s // win].record()
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
         fam = eng.family  # (a host-side field: no synchronisation)
@@ -435,6 +439,8 @@ def run_hour(eng, R, A, acts, family_requested="auto", n_steps=720, win=60):
         "left_resident_family_at_env_step": left_at,
         "share_of_replica_steps_off_resident": fam_steps["list"] / n_steps if family_requested != "list" else None,
         "stalled_replicas": eng.path_counts()["stalled"], "device_errors": eng.errors(),
+        "share_of_replicas_in_the_small_class_at_window_start": small_share,
+        "class_changes": eng.path_counts().get("class_change"), "steps_redone_by_the_full_size_launch": eng.path_counts().get("class_redo"),
         "mean_live_vehicles_per_replica_at_the_end": eng.mean_vehicles(),
         # per-replica promotion (include/pytsc_amd.h, TSC_FAMILY_AUTO): replica-steps served from the spill pool
         "spill_pool": dict(eng.spill_counts(), first_promotion_at_env_step=first_promotion,
@@ -774,6 +780,7 @@ def worker(args):
                            "(pytsc/__init__.py:52-62,164-176)",
                            "last_window_value": w[-1]["value"], "best_window_value": max(x["value"] for x in w),
                            "windows_M": [round(x["value"] / 1e6, 2) for x in w],
+                           "small_class_share_at_window_start": hour_state.get("share_of_replicas_in_the_small_class_at_window_start"),
                            "left_resident_family_at_env_step": hour_state["left_resident_family_at_env_step"],
                            "share_of_replica_steps_off_resident": hour_state["share_of_replica_steps_off_resident"],
                            "mean_live_vehicles_per_replica_at_the_end": hour_state["mean_live_vehicles_per_replica_at_the_end"]})
