@@ -48,9 +48,10 @@ class VecEngine:
                          note="dense 64-item batches of lane / lane-link work items drawn from all replicas; "
                               "one of ~22 launches per env step"),
             "resident": dict(family="resident", name="kr_step", substeps_per_launch=5,
-                             traffic_file="r04_traffic_resident.json", valu_file="r04_valu_resident.json",
-                             note="one workgroup per replica, state resident in LDS over the 5 sub-steps and "
-                                  "the measurement; the only launch of an env step"),
+                             traffic_file="r05_traffic_resident.json", valu_file="r05_valu_resident.json",
+                             note="one workgroup per replica, state resident in LDS over the 5 sub-steps and the measurement; an env "
+                                  "step = the small class's launch (512 threads, two workgroups per CU) beside the full-size "
+                                  "class's (768 threads) + a sparse redo launch: timed and counted together"),
         }
         self.obs_size = self.lib.tsc_obs_size(h)
         self.state_size = self.lib.tsc_state_size(h)
