@@ -427,7 +427,14 @@ class VecTrafficSignalNetwork:
         self.buf = self.engine.observe()
 
     def reset_all(self):
-        self.engine.reset()
+        """Every replica from an empty network.  A disrupted config draws anew for everybody (without the draw the
+        replicas fell back to the handle's set rule while `current_sets` / `info["domain_class"]` kept the old draw)."""
+        sets = None
+        if self.disrupted:
+            sets, cls = self.config.draw_sets(self.n_replicas, self._set_rng)
+            self.current_domain_class = cls.to(self.engine.device)
+            self.current_sets = sets.clone()
+        self.engine.reset(sets=sets)
         self.buf = self.engine.observe()
 
     def random_valid_actions(self, generator=None):

@@ -197,7 +197,12 @@ class DomainRandomizedEPyMARLTrafficSignalNetwork(MultiAgentEnv):
 
     def step(self, actions):
         _, reward, episode_over, _, env_info = self.current_env.step(actions[: self.current_n_agents])
-        if not self.current_env.common_reward:
+        if self.current_env.common_reward:
+            # the reference divides the mean-scalarised reward AGAIN here (wrappers/epymarl.py:326-329, on top of :104-107 inside
+            # current_env.step): kept, it is what a learner trained with the reference's wrapper has seen
+            if self.current_env.reward_scalarization == "mean":
+                reward = reward / self.current_env.tsc_env.n_agents
+        else:
             reward = self.get_local_rewards()
         return self.get_obs(), reward, episode_over, False, env_info
 

@@ -195,7 +195,10 @@ class VecDomainRandomizedEPyMARLTrafficSignalNetwork:
         if not self.common_reward:
             reward = self.get_local_rewards()
         elif self.reward_scalarization == "mean":
-            reward = reward / self.current_n_agents().to(reward.dtype)
+            # (twice: the reference's multi-map wrapper divides the already mean-scalarised reward of the map's own wrapper
+            #  again -- wrappers/epymarl.py:104-107 and :326-329)
+            n = self.current_n_agents().to(reward.dtype)
+            reward = reward / n / n
         over = self._per_slot(lambda e: e.buf["done"])
         stats = self._per_slot(lambda e: e.buf["stats"])
         from pytsc_amd.vec_env import STAT_KEYS

@@ -96,7 +96,8 @@ def test_batched_multi_map_wrapper_pads_like_the_reference_and_redraws_at_the_ho
                     assert torch.equal(local[sel][:, : nA[k]], singles[k].get_rewards()[sel])
                     # (mean scalarisation: a float32 division either way, by a tensor here and by a Python scalar there --
                     #  torch multiplies by the reciprocal in the latter form: one unit in the last place apart at most)
-                    assert torch.allclose(reward[sel], (singles[k].get_reward() / nA[k])[sel], rtol=3e-7, atol=0)
+                    # (... and the reference's multi-map wrapper divides twice: wrappers/epymarl.py:104-107,326-329)
+                    assert torch.allclose(reward[sel], (singles[k].get_reward() / nA[k] / nA[k])[sel], rtol=5e-7, atol=0)
                     assert torch.equal(inf["time_step"][sel], singles[k].buf["stats"][:, 0][sel])
                 # the reference's padding conventions (wrappers/epymarl.py:230-300)
                 assert bool((obs[sel][:, nA[k]:] == -1).all()) and bool((state[sel][:, nA[k]:] == -1).all())

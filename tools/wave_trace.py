@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--samples", type=int, default=8, help="env steps traced (workgroup 0 = replica 0 each time)")
     ap.add_argument("--rate", type=float, default=700.0, help="veh/h per entry road (150: a near-empty network -- the floor of a step)")
     ap.add_argument("--sets", type=int, default=8)
+    ap.add_argument("--waves", type=int, default=8, help="wavefronts of the traced workgroup: 8 = the small class (512 threads: what replica 0 "
+                    "runs in while it needs few records), 12 = the full-size class (PYTSC_AMD_NO_SMALL=1 in the environment)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -40,7 +42,7 @@ def main():
     buf = eng.observe()
     for _ in range(args.preroll):
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
-    NW, EV = 12, 128
+    NW, EV = 12, 128  # (the buffer holds twelve wavefronts' events; the first `--waves` are looked at)
     out = (C.c_ulonglong * (2 * EV * NW))()
     eng.lib.tsc_debug_wave_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int32]
     eng.lib.tsc_debug_wave_trace(eng.h, out, len(out))  # drop the pre-roll
@@ -50,20 +52,20 @@ def main():
         buf = eng.step(eng.random_valid_actions(buf["mask"], seed=1234, out=acts))
         n = eng.lib.tsc_debug_wave_trace(eng.h, out, len(out))
         assert n == len(out)
-        a = np.array(out[:], dtype=np.uint64).reshape(NW, EV, 2)
+        a = np.array(out[:], dtype=np.uint64).reshape(NW, EV, 2)[: args.waves]
         ids = (a[0, :, 0] >> np.uint64(56)).astype(int)
         arrive = (a[:, :, 0] & np.uint64((1 << 56) - 1)).astype(np.int64)
         leave = (a[:, :, 1] & np.uint64((1 << 56) - 1)).astype(np.int64)
         n_ev = int((ids > 0).sum())
         prev = None
         for e in range(n_ev):
-            start = leave[:, e - 1] if e else np.full(NW, arrive[:, 0].min())
+            start = leave[:, e - 1] if e else np.full(args.waves, arrive[:, 0].min())
             w = arrive[:, e] - start           # cycles each wavefront worked in this phase
             wt = leave[:, e].max() - arrive[:, e]  # ... and waited at the barrier
             work.setdefault((e, ids[e]), []).append(w)
             waitv.setdefault((e, ids[e]), []).append(wt)
     print(f"kr_step, workgroup 0 (replica 0), mean of {args.samples} env steps after {args.preroll}; cycles per wavefront between barriers")
-    print(f"{'#':>3} {'phase':24s} {'longest':>8} {'mean':>7} {'shortest':>8}   work per wavefront 0..11")
+    print(f"{'#':>3} {'phase':24s} {'longest':>8} {'mean':>7} {'shortest':>8}   work per wavefront 0..{args.waves - 1}")
     tot_long = tot_mean = 0
     for (e, i) in sorted(work):
         w = np.mean(work[(e, i)], axis=0)
