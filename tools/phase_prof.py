@@ -20,6 +20,7 @@ PHASES = ["load", "links", "spawn0", "classify", "exec", "unlink", "append", "me
 def build():
     from pytsc_amd import build as b
 
+    os.environ["PYTSC_AMD_BUILD_ANY_VGPRS"] = "1"  # (the stamps cost registers: a diagnostic build's small class may run one per CU)
     b.build(force=True, verbose=True, extra=["-DTSC_DIAG"], out=DIAG)
 
 
