@@ -289,8 +289,10 @@ typedef struct tsc_config {
    * surviving entry (> 0) of an incoming lane's position-matrix window gets val + N(0, std), clipped to [0, 1], BEFORE the
    * integer truncation of the row (the entry ends as 1 iff val + noise >= 1); empty bins and stopped vehicles
    * vanish as without noise (Q2) and take no draw.  The draws are a counter-based generator keyed on (seed, replica, engine
-   * step, signal, lane, ordinal of the surviving bin): reproducible, independent across replicas -- the law of the
-   * reference's noise, not numpy's stream (the single-env facade follows that one).  0 = off: rows bit for bit those of a
+   * step, signal, lane, ordinal of the surviving bin): the DRAWS are reproducible and independent across replicas -- the law
+   * of the reference's noise, not numpy's stream (the single-env facade follows that one).  The bin value a draw is added
+   * to is an f32 sum; on the resident family its terms are added with atomics in no fixed order, so an entry whose
+   * val + noise lies within an ulp of 1 may differ between two runs (probability ~1e-7 per entry).  0 = off: rows bit for bit those of a
    * handle without the fields.  Both kernel families (ABI 5; the resident family draws where kr_step assembles the rows, the
    * list family in k_agent from per-bin values k_measure keeps: the same key gives the same draw on either).  A handle
    * with noise runs the full-size class of the resident family only and has no stand-by (no migration, no spill pool):

@@ -206,6 +206,9 @@ class VecDomainRandomizedEPyMARLTrafficSignalNetwork:
         info = {key: stats[:, i] for i, key in enumerate(STAT_KEYS)}
         info["episode_limit"] = self.episode_limit
         info["map"] = self.slot_map
+        # 1: the slot's rows are those of this step; 0: its replica has run out of vehicle records in the map it plays (a
+        # handle with parked replicas has no stand-by: include/pytsc_amd.h, tsc_park) -- mask it out
+        info["valid"] = self._per_slot(lambda e: e.buf["valid"]) if all("valid" in e.buf for e in self.envs) else None
         return self.get_obs(), reward, over, False, info
 
     def reset(self):

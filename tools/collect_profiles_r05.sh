@@ -2,9 +2,9 @@
 # On the GPU box, from the repo root: round 5's rocprofv3 evidence into gpurun_out/r05_* (copied into profiles/ by
 # tools/summarise_profiles_r05.py).  Counters in their own passes (kernel-trace only), as MI355X_MICROARCH.md prescribes;
 # the program itself follows `--` (python3 bench.py ...), never a shell or env wrapper.
-# usage: tools/collect_profiles_r05.sh [part ...]   parts: headline configs hours curve (default: headline configs hours)
+# usage: tools/collect_profiles_r05.sh [part ...]   parts: headline c16 configs hours curve (default: headline c16 configs hours)
 root=$(pwd)
-parts=${@:-headline configs hours}
+parts=${@:-headline c16 configs hours}
 cd /tmp && export TMPDIR=/tmp
 B="python3 $root/bench.py --no-cpu-baseline --no-extras"
 stats() { # tag, bench args...
@@ -28,12 +28,14 @@ headline)
   pass tcc "TCC_HIT_sum TCC_MISS_sum" --steps 20 --warmup 5
   stats resident240
   ;;
-configs)
-  # BASELINE config 2 (16x16 @ 4096, list family) on DISTINCT demands (64 sets: every lane of a wavefront its own) and on
-  # 2 shared sets; config 4 (Jinan @ 8192)
+c16)
+  # BASELINE config 2 (16x16 @ 4096, list family) on DISTINCT demands (64 sets: every lane of a wavefront its own)
   stats c16 --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
   pass c16_fetch FETCH_SIZE --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
   pass c16_write WRITE_SIZE --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
+  ;;
+configs)
+  # ... on 2 shared sets; config 4 (Jinan @ 8192)
   stats c16_sets2 --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 2
   stats jinan --scenario jinan --replicas 8192 --steps 40 --warmup 5
   pass jinan_fetch FETCH_SIZE --scenario jinan --replicas 8192 --steps 40 --warmup 5

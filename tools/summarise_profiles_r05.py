@@ -52,10 +52,14 @@ def per_step(tag, steps, prefixes=None):
             continue
         if prefixes and not any(name.startswith(p) for p in prefixes):
             continue
+        # (kr_step: the small and the full-size launch of a step are instantiations of one template: kept apart by their
+        #  thread count, each is launched once per env step)
+        if name == "kr_step":
+            name = "kr_step<512>" if ", 512, " in row["Kernel_Name"] else ("kr_step<256 pool>" if ", 256, " in row["Kernel_Name"] else "kr_step<768>")
         per[row["Counter_Name"]][name].append(float(row["Counter_Value"]))
     tot, by = {}, {}
     for c, d in per.items():
-        once = d.get("k_stats") or d.get("kr_step_sparse") or d.get("kr_step") or next(iter(d.values()))
+        once = d.get("k_stats") or d.get("kr_step<768>") or d.get("kr_step<512>") or next(iter(d.values()))
         n_once = max(1, len(once))
         t, b = 0.0, {}
         for k, v in d.items():
