@@ -14,7 +14,7 @@ stats() { # tag, bench args...
 }
 pass() { # tag, "counters", bench args...
   tag=$1; ctr=$2; shift; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $root/gpurun_out/r05_pmc_$tag -o p -- $B "$@" > $root/gpurun_out/r05_pmc_$tag.log 2>&1
+  timeout -k 10 ${PMC_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $root/gpurun_out/r05_pmc_$tag -o p -- $B "$@" > $root/gpurun_out/r05_pmc_$tag.log 2>&1
   echo "pmc $tag rc=$?"
 }
 for part in $parts; do
@@ -31,8 +31,12 @@ headline)
 c16)
   # BASELINE config 2 (16x16 @ 4096, list family) on DISTINCT demands (64 sets: every lane of a wavefront its own)
   stats c16 --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
-  pass c16_fetch FETCH_SIZE --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
-  pass c16_write WRITE_SIZE --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
+  ;;
+c16_fetch)  # (the 64 demands take 75 s to generate and a counter pass reads every launch out: one pass per GPU call)
+  PMC_TIMEOUT=1000 pass c16_fetch FETCH_SIZE --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
+  ;;
+c16_write)
+  PMC_TIMEOUT=900 pass c16_write WRITE_SIZE --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 64
   ;;
 configs)
   # ... on 2 shared sets; config 4 (Jinan @ 8192)
