@@ -96,9 +96,13 @@ extern "C" {
  *             5 x {k_enum, k_plan, k_exec, k_commit}; k_measure, k_agent, k_net_sums, k_local_rewards,
  *             k_stats); any network size.
  *   RESIDENT  one workgroup per replica, the replica's whole state in LDS across the delta_time
- *             sub-steps and the measurement, ONE launch per env step; networks whose replica fits
- *             on chip (grids up to about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the
- *             tables do not fit it.
+ *             sub-steps and the measurement; networks whose replica fits on chip (grids up to
+ *             about 5x5, Jinan 3x4).  tsc_create returns TSC_EUNSUP if the tables do not fit it.
+ *             ABI 5: two CLASSES of workgroups step the replicas out of the same per-replica blobs
+ *             -- those that need few vehicle records in 512-thread workgroups with an LDS image of
+ *             at most 80 KB, two per CU (1.5-1.7x the rate per replica), the others in 768-thread
+ *             workgroups with the whole CU's LDS; one launch per class and env step; a replica
+ *             changes class by a byte the kernel itself sets (tsc_class_counts).
  *   AUTO      RESIDENT where it fits, else LIST.  A replica of an AUTO handle on RESIDENT that comes within resident_margin
  *             records of its capacity is PROMOTED to the handle's spill pool: its state is copied into a blob with room for
  *             every drivable bumper to bumper (up to 16320 records) and the same kernel steps it from there with its
