@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): same-box A/B of builds of the library.
 
-  python tools/ab_bench.py [--steps 40] [--warmup 5] [--rounds 2] libA.so libB.so ...
+  python tools/ab_bench.py [--steps 40] [--warmup 5] [--rounds 2] [--bench-args "--rate 150"] libA.so libB.so ...
 
 Runs bench.py's workload (no CPU baseline) once per library and round, each in a fresh process with
 pytsc_amd._lib.LIB_PATH pointed at that build, and prints ms per env step and agent-env-steps/s side by side.
@@ -32,15 +32,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--one", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--bench-args", default="", help='further bench.py arguments as ONE string, e.g. --bench-args "--rate 150 --family resident" '
+                    "(round 5: unknown options used to be passed through, and the positional `libs` swallowed their values)")
     ap.add_argument("libs", nargs="*")
-    args, extra = ap.parse_known_args()
+    args = ap.parse_args()
+    extra = args.bench_args.split()
     if args.one:
         sys.exit(one(args.one, args.steps, args.warmup, extra))
     res = {lib: [] for lib in args.libs}
     for _ in range(args.rounds):
         for lib in args.libs:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", lib, "--steps", str(args.steps), "--warmup",
-                                str(args.warmup)] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                str(args.warmup), "--bench-args", args.bench_args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             line = [x for x in p.stdout.splitlines() if x.startswith("{")]
             if p.returncode != 0 or not line:
                 print(f"{lib}: FAILED rc={p.returncode}\n{p.stderr[-2000:]}")

@@ -16,7 +16,7 @@ from pytsc_amd.vec_env import VecEngine
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-names = ("obs", "mask", "stats", "local_reward64", "global_reward64", "agent_stats", "phase", "state", "done", "terminated")
+names = ("obs", "mask", "stats", "local_reward64", "global_reward64", "agent_stats", "phase", "state", "done", "terminated", "phase_scores")
 for case in range(n_cases):
     scen = str(rng.choice(["syn_1x1", "syn_2x2", "syn_3x3", "syn_4x4"]))
     space = str(rng.choice(["phase_selection", "phase_switch"]))
@@ -25,7 +25,7 @@ for case in range(n_cases):
     rate = float(rng.choice([300.0, 700.0, 1200.0, 1800.0]))
     family = str(rng.choice(["resident", "list"]))
     R = int(rng.choice([3, 6, 9]))
-    steps = 70
+    steps = int(rng.choice([70, 70, 160]))  # (160 at the higher rates: the 3x3 / 4x4 cross from the small class to the full-size one)
 
     def tables():
         cfg = Config(scen, signal={"action_space": space, "round_robin": rr, "visibility": vis},
