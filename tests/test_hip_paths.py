@@ -175,10 +175,12 @@ def test_overlap_leaver_marks_the_replica_dirty(oracle_lib):
     eng.close()
 
 
-def test_async_caller_across_the_migration_threshold(oracle_lib):
+@pytest.mark.parametrize("how", ["state", "replay"])
+def test_async_caller_across_the_migration_threshold(oracle_lib, how, monkeypatch):
     """A caller that never waits: 190 env steps enqueued back to back (actions precomputed, outputs copied aside on the
     stream) on an AUTO handle whose replicas outgrow the resident family on the way.  The handle holds the caller back
-    to 16 steps ahead of the overflow flag, migrates by replaying its log, and every step's outputs equal the oracle's;
+    to 16 steps ahead of the overflow flag, migrates (round 5: by writing the blobs' state across; `replay`: by replaying
+    its log, PYTSC_AMD_MIGRATE=replay), and every step's outputs equal the oracle's;
     no device error, no stalled replica (a margin of 256 records outlasts 16 steps of this demand)."""
     import torch
 
@@ -186,6 +188,7 @@ def test_async_caller_across_the_migration_threshold(oracle_lib):
 
     kw = dict(flow_rate=1500.0, n_flow_sets=2, sim_length=1100, episode_limit=400)
     R, steps = 6, 190
+    monkeypatch.setenv("PYTSC_AMD_MIGRATE", how)
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
     rng = np.random.default_rng(21)
     out = orc.observe()
@@ -217,7 +220,7 @@ def test_async_caller_across_the_migration_threshold(oracle_lib):
     eng.close()
 
 
-def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(oracle_lib):
+def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(oracle_lib, capfd):
     """resident_margin 1: the flag is raised only when a replica is all but full, so with a caller 16 steps ahead some
     replica does run out of records.  It stalls (keeps the state and outputs of its last completed step, no error), the
     others carry on; once the host has seen the flag the replay on the list family repairs everything: from the
@@ -252,6 +255,7 @@ def test_replica_that_runs_out_of_records_stalls_and_the_migration_repairs_it(or
     first_list = fam.index("list")
     c = eng.path_counts()
     assert c["stalled"] >= 1, c
+    assert "state written across" not in capfd.readouterr().err  # (a stalled replica's blob is steps old: the log is replayed)
     # The caller is told which rows are stale (the reference never returns a stale observation,
     # pytsc/__init__.py:178-182): a replica's rows equal the oracle's wherever valid == 1 -- every replica, every step --,
     # valid == 0 exactly for the stalled replicas, only inside the run-ahead window before the migration, and a row that

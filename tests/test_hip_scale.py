@@ -271,10 +271,12 @@ def test_full_size_properties_jinan_r8192(family):
     eng.close()
 
 
-def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_lib):
+@pytest.mark.parametrize("how", ["state", "replay"])
+def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_lib, how, monkeypatch, capfd):
     """kernel_family AUTO: when a replica of the resident family comes within 256 vehicle records of its capacity the
-    handle moves itself to the list family by replaying its logged resets / actions (deterministic engine), and
-    carries on there.  Heavy demand on a 3x3 grid with a capacity of 1472 records, partial restarts in between:
+    handle moves itself to the list family -- `state` (round 5, the default): no replica has stalled, so the state of every
+    blob is written across (kr_to_list); `replay` (PYTSC_AMD_MIGRATE=replay; what a handle with a stalled replica still
+    does): by replaying its logged resets / actions (deterministic engine) -- and carries on there.  Heavy demand on a 3x3 grid with a capacity of 1472 records, partial restarts in between:
     every step before, across and after the migration equals the oracle, and no device error is ever raised."""
     import torch
 
@@ -282,6 +284,7 @@ def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_
 
     kw = dict(flow_rate=1500.0, n_flow_sets=2, sim_length=900, episode_limit=40)
     R = 6
+    monkeypatch.setenv("PYTSC_AMD_MIGRATE", how)
     eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_spill_limit=-1, **kw), family="auto")  # (no spill pool: whole-handle migration)
     assert eng.family == "resident"
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
@@ -308,6 +311,7 @@ def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_
             buf = eng.observe()
             assert np.array_equal(buf["obs"].cpu().numpy(), out.obs)
     assert migrated_at is not None and 25 < migrated_at < 160, migrated_at
+    assert ("state written across" in capfd.readouterr().err) == (how == "state")
     for r in range(R):
         a, b = orc.snapshot(r), eng.snapshot(r)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), r
@@ -316,7 +320,8 @@ def test_resident_handle_migrates_to_the_list_family_before_it_overflows(oracle_
     eng.close()
 
 
-def test_migrated_handle_returns_to_the_resident_family_at_a_full_restart(oracle_lib):
+@pytest.mark.parametrize("how", ["state", "replay"])
+def test_migrated_handle_returns_to_the_resident_family_at_a_full_restart(oracle_lib, how, monkeypatch):
     """kernel_family AUTO, `sequential` flow sets: run resident -> (capacity) -> list family -> full restart -> resident
     again -> (capacity) -> list family a second time.  The second replay starts at that full restart, not at
     tsc_create: all it needs of the past are the restart counters (the flow set of a replica is derived from them),
@@ -328,6 +333,7 @@ def test_migrated_handle_returns_to_the_resident_family_at_a_full_restart(oracle
 
     kw = dict(flow_rate=1500.0, n_flow_sets=3, sim_length=900, episode_limit=40, flow_rate_type="sequential")
     R = 4
+    monkeypatch.setenv("PYTSC_AMD_MIGRATE", how)
     eng = VecEngine(_tables("syn_3x3", R, resident_capacity=1472, resident_spill_limit=-1, **kw), family="auto")  # (no spill pool: whole-handle migration)
     orc = oracle_lib.Oracle(_tables("syn_3x3", R, **kw))
     fam = lambda: eng.lib.tsc_kernel_family(eng.h)  # 1: list, 2: resident

@@ -107,8 +107,13 @@ def test_a_replica_that_stalls_is_promoted_and_caught_up(oracle_lib):
     eng.close()
 
 
-def test_beyond_the_pool_limit_the_handle_moves_to_the_list_family(oracle_lib):
+@pytest.mark.parametrize("how", ["state", "replay"])
+def test_beyond_the_pool_limit_the_handle_moves_to_the_list_family(oracle_lib, how, monkeypatch, capfd):
+    """(round 5) `state`: the blobs -- the replicas' own and the pool's two -- are written across into the list family's
+    arrays (kr_to_list); `replay`: the log is replayed, as in rounds 3-4 (PYTSC_AMD_MIGRATE=replay)."""
     import torch
+
+    monkeypatch.setenv("PYTSC_AMD_MIGRATE", how)
 
     from pytsc_amd.vec_env import VecEngine
 
@@ -121,6 +126,7 @@ def test_beyond_the_pool_limit_the_handle_moves_to_the_list_family(oracle_lib):
         fam.append(eng.family)
         assert np.array_equal(buf["obs"].cpu().numpy(), exp[s][0]) and np.array_equal(buf["stats"].cpu().numpy(), exp[s][1]), s
     assert fam[0] == "resident" and fam[-1] == "list"
+    assert ("state written across" in capfd.readouterr().err) == (how == "state")
     for r in range(R):
         assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
     assert eng.errors() == 0

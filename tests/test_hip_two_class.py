@@ -105,3 +105,49 @@ def test_one_class_and_two_classes_agree_and_the_small_launch_is_skipped_when_no
     assert two.errors() == 0 and one.errors() == 0
     two.close()
     one.close()
+
+
+def test_a_two_class_handle_that_outgrows_the_family_writes_its_state_across(oracle_lib, capfd):
+    """(round 5, the demand cliff of VERDICT r4 item 6) An `auto` handle with two classes and a spill pool of one slot: at
+    1 500 veh/h the first replica to come near its capacity is promoted, the second one takes the whole handle to the list
+    family -- no replica has stalled, so the blobs' state (full-size replicas, the half that was restarted and is in the
+    small class again, the pool's replica) is written across by kr_to_list instead of replaying 200-odd logged steps.
+    Every output of every step before, at and after the hand-over is the oracle's, every vehicle too."""
+    import torch
+
+    from pytsc_amd.vec_env import VecEngine
+
+    R, steps = 8, 330
+    hip = dict(sim_length=2000, episode_limit=2000)
+    eng = VecEngine(_tables(R, 1500.0, resident_capacity=2304, resident_spill_limit=1, **hip), family="auto")
+    assert eng.family == "resident" and eng.class_counts() == (R, 0)
+    orc = oracle_lib.Oracle(_tables(R, 1500.0, **hip))
+    orc.reset(sets=np.arange(R, dtype=np.int32) % 4)
+    buf, out = eng.observe(), orc.observe()
+    moved_at, classes_before = None, None
+    for s in range(steps):
+        acts = eng.random_valid_actions(buf["mask"], seed=9)
+        if moved_at is None:
+            classes_before = eng.class_counts()
+        buf = eng.step(acts)
+        out = orc.step(acts.cpu().numpy())
+        for k in NAMES:
+            assert np.array_equal(buf[k].cpu().numpy(), getattr(out, k)), (k, s)
+        assert bool(buf["valid"].all()), s
+        if moved_at is None and eng.family == "list":
+            moved_at = s
+        if s == 120:  # half of the replicas start again: they are small when the others ask for room
+            mask = (np.arange(R) % 2 == 0).astype(np.uint8)
+            orc.reset(mask)
+            eng.reset(torch.tensor(mask))
+            out, buf = orc.observe(), eng.observe()
+        if moved_at is not None and s >= moved_at + 40:
+            break
+    assert moved_at is not None and moved_at > 130, moved_at
+    assert classes_before[0] >= 1 and classes_before[1] >= 1, classes_before  # both classes were populated at the hand-over
+    assert "state written across" in capfd.readouterr().err
+    for r in range(R):
+        assert all(np.array_equal(x, y) for x, y in zip(orc.snapshot(r), eng.snapshot(r))), r
+    assert eng.errors() == 0 and orc.errors() == 0 and eng.path_counts()["stalled"] == 0
+    eng.close()
+    orc.close()
