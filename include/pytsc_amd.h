@@ -110,7 +110,9 @@ extern "C" {
  *             results, the other replicas untouched.  Once more than resident_spill_limit replicas have asked, the whole
  *             handle moves to LIST instead, as follows.  An AUTO handle on RESIDENT keeps the LIST arrays as a stand-by and
  *             logs resets / actions on the device: when a replica comes within resident_margin vehicle records of
- *             its capacity the handle moves to LIST by replaying the log (same results).  The flag travels to the host
+ *             its capacity the handle moves to LIST (same results): while no replica has stalled, by writing the state of
+ *             every replica across into the LIST arrays (round 5: a millisecond); with a stalled replica -- its state is
+ *             steps old -- by replaying the log.  The flag travels to the host
  *             behind every step and is read, without synchronising, by the next tsc_step; a caller that enqueues steps
  *             without waiting is held back so that it never runs more than 16 steps ahead of the flag.  Should a replica
  *             run out of records all the same (more than the margin gained within those steps), it STALLS: its state
