@@ -50,8 +50,8 @@ class VecEngine:
             "resident": dict(family="resident", name="kr_step", substeps_per_launch=5,
                              traffic_file="r05_traffic_resident.json", valu_file="r05_valu_resident.json",
                              note="one workgroup per replica, state resident in LDS over the 5 sub-steps and the measurement; an env "
-                                  "step = the small class's launch (512 threads, two workgroups per CU) beside the full-size "
-                                  "class's (768 threads) + a sparse redo launch: timed and counted together"),
+                                  "step = the small class's launch (512 threads, two workgroups per CU) and, behind it, the full-size "
+                                  "class's (768 threads; it also redoes a step the small class abandoned): timed and counted together"),
         }
         self.obs_size = self.lib.tsc_obs_size(h)
         self.state_size = self.lib.tsc_state_size(h)

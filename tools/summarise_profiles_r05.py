@@ -1,5 +1,5 @@
 """gpurun_out/r05_* (tools/collect_profiles_r05.sh) -> profiles/r05_*: rocprofv3 kernel tables, the per-env-step counter sums
-of the resident family's launches (two classes + the redo launch: all instantiations of kr_step / kr_step_sparse together),
+of the resident family's launches (the small class's launch + the full-size class's: all instantiations of kr_step together),
 the traffic and VALU records bench.py quotes, the 16x16 and Jinan records, the hour(s)."""
 import collections
 import csv
@@ -75,7 +75,7 @@ def main():
     os.makedirs(P, exist_ok=True)
     for tag in ("resident", "resident240", "c16", "c16_sets2", "jinan"):
         kernel_stats(tag)
-    # ---- resident family, driver command: counters per env step (small launch + full-size launch + redo launch)
+    # ---- resident family, driver command: counters per env step (small launch + full-size launch)
     allc = {}
     for tag in ("fetch", "write", "sq1", "sq2", "tcc"):
         t, _ = per_step(tag, 20, ("kr_step",))
@@ -83,7 +83,7 @@ def main():
     bl = bench_line(os.path.join(G, "r05_stats_resident.log"))
     if allc:
         with open(os.path.join(P, "r05_resident_pmc_summary.txt"), "w") as o:
-            o.write("kr_step (small class + full-size class + redo launch: every launch of an env step summed), mean per ENV STEP over the "
+            o.write("kr_step (small class's launch + full-size class's: every launch of an env step summed), mean per ENV STEP over the "
                     "last 20 env steps of `bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5` (after the 150-step pre-roll), "
                     "separate rocprofv3 --pmc passes, kernel-trace only\n")
             for c in sorted(allc):
@@ -101,8 +101,8 @@ def main():
                "fetch_size_kb_per_launch": allc["FETCH_SIZE"], "write_size_kb_per_launch": allc["WRITE_SIZE"],
                "bytes_per_launch": (2.0 * allc["FETCH_SIZE"] + allc["WRITE_SIZE"]) * 1024.0,
                "algorithmic_bytes_per_launch": bl_f["roofline"]["bytes_per_agent_env_step"] * R * A,
-               "formula": "2 x FETCH_SIZE + WRITE_SIZE (kB x 1024) summed over the launches of an env step (small class, full-size class, "
-                          "redo launch), mean of the last 20 env steps",
+               "formula": "2 x FETCH_SIZE + WRITE_SIZE (kB x 1024) summed over the launches of an env step (small class, full-size class), "
+                          "mean of the last 20 env steps",
                "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace-only passes (tools/collect_profiles_r05.sh); "
                       "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes: MI355X_MICROARCH.md, HBM)"}
         rec["ratio_to_algorithmic"] = rec["bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
