@@ -78,7 +78,8 @@ def test_a_step_abandoned_inside_the_small_class_is_redone_by_the_full_size_laun
     """PYTSC_AMD_CLS_MARGIN=0: a replica leaves the small class only by running out of records WITHIN a step -- nothing has
     been stored by then, the full-size launch of the same tsc_step steps it from the same state.  A small capacity
     (PYTSC_AMD_SMALL_P) brings that forward."""
-    hist, c = _run(oracle_lib, 48, 1100.0, 140, env={"PYTSC_AMD_CLS_MARGIN": "0", "PYTSC_AMD_SMALL_P": "1024"}, sim_length=1200)
+    hist, c = _run(oracle_lib, 48, 1100.0, 140, env={"PYTSC_AMD_CLS_MARGIN": "0", "PYTSC_AMD_SMALL_P": "1024",
+                                                         "PYTSC_AMD_SMALL_HEAVY_PCT": "0"}, sim_length=1200)  # (... and the small launch is never left out for small replicas near their capacity: every hand-over is a redo)
     assert c["class_redo"] >= 40, c  # (nearly) every replica went over through the redo path
     assert any(b == 48 for _, b in hist)
 
