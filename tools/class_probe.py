@@ -24,7 +24,7 @@ for w in range(36):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 100.0
     c = eng.path_counts()
-    rows.append((w * 10, round(ms, 4), cs, cb, c["class_redo"] - prev["class_redo"], c["class_change"] - prev["class_change"], round(eng.mean_vehicles(), 0)))
+    rows.append((w * 10, round(ms, 4), cs, cb, c["class_redo"] - prev["class_redo"], c["class_change"] - prev["class_change"], round(eng.mean_vehicles(), 0), c["serial_scan"] - prev["serial_scan"]))
     prev = c
     print(rows[-1], flush=True)
 print("total ms", sum(r[1] for r in rows) * 10)

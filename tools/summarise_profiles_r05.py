@@ -176,9 +176,14 @@ def main():
                           "small_class_share_at_window_start": d.get("share_of_replicas_in_the_small_class_at_window_start"),
                           "mean_live_vehicles_per_replica_at_the_end": d["mean_live_vehicles_per_replica_at_the_end"],
                           "stalled_replicas": d["stalled_replicas"], "device_errors": d["device_errors"]})
+            before = bench_line(os.path.join(P, f"r05_hour_rate{r}_log_replay.json"))  # (kept from before kr_to_list)
+            if before:
+                curve[-1]["with_log_replay_before_kr_to_list"] = {"value": before["value"], "windows_M": [round(w["value"] / 1e6, 1) for w in before["windows"]]}
     if curve:
         with open(os.path.join(P, "r05_demand_curve.json"), "w") as o:
-            json.dump({"workload": "4x4 @ 4096, 256 flow sets, one simulated hour from empty + restart, every replica at the same rate", "curve": curve}, o, indent=1)
+            json.dump({"workload": "4x4 @ 4096, 256 flow sets, one simulated hour from empty + restart, every replica at the same rate", "curve": curve,
+                       "note": "a handle that leaves the resident family writes its replicas' state across (kr_to_list) unless a replica had stalled; "
+                               "with_log_replay_before_kr_to_list: the same hour while the hand-over replayed the log"}, o, indent=1)
         print(json.dumps([(c["rate_veh_per_h_per_entry_road"], round(c["value"] / 1e6, 1), c["left_resident_family_at_env_step"]) for c in curve]))
 
 
