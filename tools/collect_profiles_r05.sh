@@ -2,7 +2,7 @@
 # On the GPU box, from the repo root: round 5's rocprofv3 evidence into gpurun_out/r05_* (copied into profiles/ by
 # tools/summarise_profiles_r05.py).  Counters in their own passes (kernel-trace only), as MI355X_MICROARCH.md prescribes;
 # the program itself follows `--` (python3 bench.py ...), never a shell or env wrapper.
-# usage: tools/collect_profiles_r05.sh [part ...]   parts: headline c16 configs hours curve (default: headline c16 configs hours)
+# usage: tools/collect_profiles_r05.sh [part ...]   parts: headline c16 c16_fetch c16_write configs jinan hours curve (default: headline c16 configs hours)
 root=$(pwd)
 parts=${@:-headline c16 configs hours}
 cd /tmp && export TMPDIR=/tmp
@@ -41,6 +41,11 @@ c16_write)
 configs)
   # ... on 2 shared sets; config 4 (Jinan @ 8192)
   stats c16_sets2 --rows 16 --cols 16 --replicas 4096 --steps 10 --warmup 2 --flow-sets 2
+  stats jinan --scenario jinan --replicas 8192 --steps 40 --warmup 5
+  pass jinan_fetch FETCH_SIZE --scenario jinan --replicas 8192 --steps 40 --warmup 5
+  pass jinan_write WRITE_SIZE --scenario jinan --replicas 8192 --steps 40 --warmup 5
+  ;;
+jinan)
   stats jinan --scenario jinan --replicas 8192 --steps 40 --warmup 5
   pass jinan_fetch FETCH_SIZE --scenario jinan --replicas 8192 --steps 40 --warmup 5
   pass jinan_write WRITE_SIZE --scenario jinan --replicas 8192 --steps 40 --warmup 5
