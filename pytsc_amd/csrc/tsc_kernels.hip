@@ -2616,14 +2616,8 @@ __global__ void k_count_vehicles(DevNet N, DevState S, unsigned long long *total
 
 #include "tsc_resident.inc"
 
-// Action log of a handle that may migrate from the resident to the list family (tsc_api.inc): one byte per action.
-__global__ void k_log_actions(signed char *dst, signed char *dst2, const int *src, int n) { // (either destination may be null)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const signed char v = (signed char)src[i];
-  if (dst) dst[i] = v;
-  if (dst2) dst2[i] = v;
-}
+// Action log of a handle that may migrate from the resident to the list family (tsc_api.inc): one byte per action, written
+// by kr_step's launch over all replicas (tsc_resident.inc); read back here.
 __global__ void k_unlog_actions(int *dst, const signed char *src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (int)src[i];
